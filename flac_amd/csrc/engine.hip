@@ -1,0 +1,432 @@
+// Host side of the C ABI declared in include/flac_amd_engine.h: parameter resolution,
+// window tables, device workspace, and the launch sequence of the encoder stages.
+// No CPU implementation of any stage lives here: without a HIP device every compute entry
+// point fails with FLACAMD_E_NO_DEVICE.
+#include "engine_types.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+extern "C" {
+void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+void fa_launch_model(const FaCfg *c, const FaWork *w, hipStream_t st);
+size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg);
+void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st);
+size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out);
+void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st);
+}
+
+static thread_local char g_last_error[256] = "";
+
+static int hip_fail(hipError_t e, const char *what)
+{
+	snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
+	return e == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE;
+}
+#define HIP_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return hip_fail(e_, #call); } while(0)
+
+extern "C" const char *flacamd_last_error(void) { return g_last_error; }
+
+extern "C" const char *flacamd_strerror(int code)
+{
+	switch(code) {
+	case FLACAMD_OK: return "ok";
+	case FLACAMD_E_INVALID_ARGUMENT: return "invalid argument";
+	case FLACAMD_E_UNSUPPORTED: return "outside the engine limits";
+	case FLACAMD_E_NO_DEVICE: return "no HIP device";
+	case FLACAMD_E_OUT_OF_MEMORY: return "out of device memory";
+	case FLACAMD_E_DEVICE: return "HIP call failed";
+	case FLACAMD_E_CAPACITY: return "capacity too small";
+	case FLACAMD_E_FRAME_OVERFLOW: return "frame exceeded its slot";
+	case FLACAMD_E_BAD_STREAM: return "bad stream";
+	default: return "unknown error";
+	}
+}
+
+extern "C" int flacamd_device_count(void)
+{
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// ------------------------------------------------------------------ parameters
+
+static unsigned ilog2u(uint32_t v) { unsigned l = 0; while(v >>= 1) l++; return l; }
+
+extern "C" void flacamd_params_preset(flacamd_params *p, unsigned level)
+{
+	// compression_levels_[] (stream_encoder.c:127-148): mid/side, loose, max lpc order, exhaustive, max partition order
+	static const uint8_t t[9][5] = { {0,0,0,0,3},{1,1,0,0,3},{1,0,0,0,3},{0,0,6,0,4},{1,1,8,0,4},{1,0,8,0,5},{1,0,8,0,6},{1,0,8,1,6},{1,0,12,1,6} };
+	if(level > 8) level = 8;
+	p->do_mid_side = t[level][0]; p->loose_mid_side = t[level][1]; p->max_lpc_order = t[level][2];
+	p->qlp_coeff_precision = 0; p->do_qlp_coeff_prec_search = 0; p->do_exhaustive_model_search = t[level][3];
+	p->min_residual_partition_order = 0; p->max_residual_partition_order = t[level][4];
+	p->num_apodizations = 1; p->apod_type[0] = FLACAMD_WIN_TUKEY; p->apod_param[0] = 0.5f; // stream_encoder.c:1481-1483
+}
+
+extern "C" int flacamd_params_resolve(flacamd_params *p)
+{
+	if(!p) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->channels == 0 || p->channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->channels != 2) { p->do_mid_side = 0; p->loose_mid_side = 0; }
+	else if(!p->do_mid_side) p->loose_mid_side = 0;
+	if(p->bits_per_sample < 4 || p->bits_per_sample > 24) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->sample_rate == 0 || p->sample_rate > 655350) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->blocksize == 0) p->blocksize = p->max_lpc_order == 0 ? 1152 : 4096;
+	if(p->blocksize < 16 || p->blocksize > 65535) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->max_lpc_order > FLACAMD_MAX_LPC_ORDER) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->blocksize < p->max_lpc_order) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->qlp_coeff_precision == 0) {
+		const unsigned bs = p->blocksize;
+		if(p->bits_per_sample < 16) { const unsigned v = 2 + p->bits_per_sample / 2; p->qlp_coeff_precision = v > FA_MIN_QLP_PRECISION ? v : FA_MIN_QLP_PRECISION; }
+		else if(p->bits_per_sample == 16) p->qlp_coeff_precision = bs <= 192 ? 7 : bs <= 384 ? 8 : bs <= 576 ? 9 : bs <= 1152 ? 10 : bs <= 2304 ? 11 : bs <= 4608 ? 12 : 13;
+		else p->qlp_coeff_precision = bs <= 384 ? FA_MAX_QLP_PRECISION - 2 : bs <= 1152 ? FA_MAX_QLP_PRECISION - 1 : FA_MAX_QLP_PRECISION;
+	}
+	else if(p->qlp_coeff_precision < FA_MIN_QLP_PRECISION || p->qlp_coeff_precision > FA_MAX_QLP_PRECISION) return FLACAMD_E_INVALID_ARGUMENT;
+	if(p->max_residual_partition_order > 15) p->max_residual_partition_order = 15;
+	if(p->min_residual_partition_order >= p->max_residual_partition_order) p->min_residual_partition_order = p->max_residual_partition_order;
+	if(p->num_apodizations == 0) { p->num_apodizations = 1; p->apod_type[0] = FLACAMD_WIN_TUKEY; p->apod_param[0] = 0.5f; }
+	if(p->num_apodizations > FLACAMD_MAX_APODIZATIONS) return FLACAMD_E_INVALID_ARGUMENT;
+	// engine limits
+	if(p->blocksize > FLACAMD_MAX_BLOCKSIZE) return FLACAMD_E_UNSUPPORTED;
+	if(p->max_residual_partition_order > FLACAMD_MAX_PARTITION_ORDER) return FLACAMD_E_UNSUPPORTED;
+	return FLACAMD_OK;
+}
+
+// window.c:49-223.  The float/double mix of every sub-expression is the reference's: the
+// value stored as float depends on it.
+extern "C" void flacamd_window(uint32_t type, float param, int32_t L, float *w)
+{
+	const int32_t N = L - 1; int32_t n;
+	const double N2 = (double)N / 2.;
+	switch(type) {
+	case FLACAMD_WIN_BARTLETT:
+		if(L & 1) { for(n = 0; n <= N/2; n++) w[n] = 2.0f * n / (float)N; for(; n <= N; n++) w[n] = 2.0f - 2.0f * n / (float)N; }
+		else { for(n = 0; n <= L/2-1; n++) w[n] = 2.0f * n / (float)N; for(; n <= N; n++) w[n] = 2.0f - 2.0f * (N-n) / (float)N; }
+		break;
+	case FLACAMD_WIN_BARTLETT_HANN:
+		for(n = 0; n < L; n++) w[n] = (float)(0.62f - 0.48f * fabs((float)n/(float)N+0.5f) + 0.38f * cos(2.0f * M_PI * ((float)n/(float)N+0.5f)));
+		break;
+	case FLACAMD_WIN_BLACKMAN:
+		for(n = 0; n < L; n++) w[n] = (float)(0.42f - 0.5f * cos(2.0f * M_PI * n / N) + 0.08f * cos(4.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_BLACKMAN_HARRIS_4TERM:
+		for(n = 0; n <= N; n++) w[n] = (float)(0.35875f - 0.48829f * cos(2.0f * M_PI * n / N) + 0.14128f * cos(4.0f * M_PI * n / N) - 0.01168f * cos(6.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_CONNES:
+		for(n = 0; n <= N; n++) { double k = ((double)n - N2) / N2; k = 1.0f - k * k; w[n] = (float)(k * k); }
+		break;
+	case FLACAMD_WIN_FLATTOP:
+		for(n = 0; n < L; n++) w[n] = (float)(1.0f - 1.93f * cos(2.0f * M_PI * n / N) + 1.29f * cos(4.0f * M_PI * n / N) - 0.388f * cos(6.0f * M_PI * n / N) + 0.0322f * cos(8.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_GAUSS:
+		for(n = 0; n <= N; n++) { const double k = ((double)n - N2) / (param * N2); w[n] = (float)exp(-0.5f * k * k); }
+		break;
+	case FLACAMD_WIN_HAMMING:
+		for(n = 0; n < L; n++) w[n] = (float)(0.54f - 0.46f * cos(2.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_HANN:
+		for(n = 0; n < L; n++) w[n] = (float)(0.5f - 0.5f * cos(2.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_KAISER_BESSEL:
+		for(n = 0; n < L; n++) w[n] = (float)(0.402f - 0.498f * cos(2.0f * M_PI * n / N) + 0.098f * cos(4.0f * M_PI * n / N) - 0.001f * cos(6.0f * M_PI * n / N));
+		break;
+	case FLACAMD_WIN_NUTTALL:
+		for(n = 0; n < L; n++) w[n] = (float)(0.3635819f - 0.4891775f*cos(2.0f*M_PI*n/N) + 0.1365995f*cos(4.0f*M_PI*n/N) - 0.0106411f*cos(6.0f*M_PI*n/N));
+		break;
+	case FLACAMD_WIN_RECTANGLE:
+		for(n = 0; n < L; n++) w[n] = 1.0f;
+		break;
+	case FLACAMD_WIN_TRIANGLE: // window.c:179 reads "L+1/2", i.e. L: the odd-length branch never runs its second loop
+		if(L & 1) { for(n = 1; n <= L+1/2; n++) w[n-1] = 2.0f * n / ((float)L + 1.0f); for(; n <= L; n++) w[n-1] = - (float)(2 * (L - n + 1)) / ((float)L + 1.0f); }
+		else { for(n = 1; n <= L/2; n++) w[n-1] = 2.0f * n / (float)L; for(; n <= L; n++) w[n-1] = ((float)(2 * (L - n)) + 1.0f) / (float)L; }
+		break;
+	case FLACAMD_WIN_WELCH:
+		for(n = 0; n <= N; n++) { const double k = ((double)n - N2) / N2; w[n] = (float)(1.0f - k * k); }
+		break;
+	case FLACAMD_WIN_TUKEY: default:
+		if(param <= 0.0) flacamd_window(FLACAMD_WIN_RECTANGLE, 0, L, w);
+		else if(param >= 1.0) flacamd_window(FLACAMD_WIN_HANN, 0, L, w);
+		else {
+			const int32_t Np = (int32_t)(param / 2.0f * L) - 1;
+			flacamd_window(FLACAMD_WIN_RECTANGLE, 0, L, w);
+			if(Np > 0) for(n = 0; n <= Np; n++) {
+				w[n] = (float)(0.5f - 0.5f * cos(M_PI * n / Np));
+				w[L-Np-1+n] = (float)(0.5f - 0.5f * cos(M_PI * (n+Np) / Np));
+			}
+		}
+		break;
+	}
+}
+
+// ------------------------------------------------------------------ encoder object
+
+struct flacamd_encoder {
+	int device;
+	flacamd_params p;
+	FaCfg cfg;             // static fields filled at create, batch fields per call
+	FaWork work;
+	uint32_t max_frames;
+	uint32_t cand_group;   // candidates evaluated per LDS round in the search kernel
+	int sum64;             // 64-bit |residual| partial sums needed
+	void *arena; size_t arena_bytes;
+	void *d_pcm_stage; size_t pcm_stage_bytes;   // host-entry staging
+	uint8_t *d_out_stage; size_t out_stage_bytes;
+	uint32_t *d_fb_stage;
+	uint32_t last_F, last_G;
+	int timing;
+	hipEvent_t ev[7];
+	float last_ms[6];
+	int have_timing;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" const flacamd_params *flacamd_encoder_params(const flacamd_encoder *e) { return e ? &e->p : 0; }
+
+extern "C" size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nframes)
+{
+	return e ? (size_t)nframes * e->cfg.slot_bytes : 0;
+}
+
+extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const flacamd_params *params, uint32_t max_frames)
+{
+	if(!out || !params || max_frames == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	*out = 0;
+	if(flacamd_device_count() <= device || device < 0) { snprintf(g_last_error, sizeof g_last_error, "no HIP device %d", device); return FLACAMD_E_NO_DEVICE; }
+	flacamd_encoder *e = (flacamd_encoder*)calloc(1, sizeof *e);
+	if(!e) return FLACAMD_E_OUT_OF_MEMORY;
+	e->p = *params;
+	int rc = flacamd_params_resolve(&e->p);
+	if(rc != FLACAMD_OK) { free(e); return rc; }
+	e->device = device; e->max_frames = max_frames;
+	HIP_TRY(hipSetDevice(device));
+
+	const flacamd_params &p = e->p;
+	FaCfg &c = e->cfg;
+	memset(&c, 0, sizeof c);
+	c.channels = p.channels; c.bps = p.bits_per_sample; c.rate = p.sample_rate; c.N = p.blocksize;
+	c.midside = (p.channels == 2 && p.do_mid_side) ? 1u : 0u;
+	c.nsig = c.midside ? 4u : p.channels;
+	c.loose = p.loose_mid_side;
+	{ // stream_encoder.c:878-890
+		unsigned lp = (unsigned)((double)p.sample_rate * 0.4 / (double)p.blocksize + 0.5);
+		c.loose_period = lp ? lp : 1u;
+	}
+	c.max_lpc_order = p.max_lpc_order; c.qlp_precision = p.qlp_coeff_precision; c.prec_search = p.do_qlp_coeff_prec_search;
+	c.exhaustive = p.do_exhaustive_model_search; c.min_po = p.min_residual_partition_order; c.max_po = p.max_residual_partition_order;
+	c.disable_constant = p.disable_constant; c.disable_fixed = p.disable_fixed; c.disable_verbatim = p.disable_verbatim;
+	c.num_apod = p.num_apodizations; c.lag = p.max_lpc_order + 1u;
+	c.k_limit = p.bits_per_sample > 16 ? 31u : 15u;
+	c.wide_fixed = (p.bits_per_sample + ilog2u(p.blocksize) + 1 > 30) ? 1u : 0u; // stream_encoder.c:894
+	{
+		const uint32_t nfixed = p.do_exhaustive_model_search ? 5u : 1u;
+		const uint32_t norders = p.max_lpc_order ? (p.do_exhaustive_model_search ? p.max_lpc_order : 1u) : 0u;
+		const uint32_t nprec = p.do_qlp_coeff_prec_search ? (FA_MAX_QLP_PRECISION - FA_MIN_QLP_PRECISION + 1u) : 1u;
+		c.max_cand = nfixed + p.num_apodizations * norders * nprec;
+	}
+	{
+		// frame slot: header + per channel (verbatim bound with slack + subframe head) + footer
+		const size_t maxbps = p.bits_per_sample + 1u;
+		const size_t sub = ((size_t)p.blocksize * (maxbps + 1u) + 8u + 32u + 32u * (maxbps + 15u) + 64u + 7u) / 8u + 8u;
+		c.slot_bytes = (uint32_t)align_up(16u + p.channels * sub + 2u + 16u, 16u);
+	}
+	e->cand_group = c.max_cand < 24u ? c.max_cand : 24u;
+	if(e->cand_group == 0) e->cand_group = 1;
+	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
+	if(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }
+	if(fa_pack_lds_bytes(&c, 0) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }
+
+	// one arena for all per-batch arrays
+	const size_t G = (size_t)max_frames * c.nsig, F = max_frames;
+	const size_t qrows = p.max_lpc_order ? p.max_lpc_order : 1u;
+	size_t off = 0;
+	auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
+		o_ncand = take(G * 4), o_chdr = take((size_t)c.max_cand * G * 4), o_cq = take((size_t)c.max_cand * qrows * G * 4),
+		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4),
+		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4);
+	e->arena_bytes = off;
+	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
+	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
+	uint8_t *b = (uint8_t*)e->arena;
+	FaWork &w = e->work;
+	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
+	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_chdr); w.cand_q = (int32_t*)(b + o_cq);
+	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg);
+	w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
+
+	// window tables, computed on the host exactly once per stream (resize_buffers_, stream_encoder.c:2318-2373)
+	{
+		float *hw = (float*)malloc(sizeof(float) * (size_t)c.num_apod * c.N);
+		if(!hw) { hipFree(e->arena); free(e); return FLACAMD_E_OUT_OF_MEMORY; }
+		for(uint32_t a = 0; a < c.num_apod; a++) flacamd_window(p.apod_type[a], p.apod_param[a], (int32_t)c.N, hw + (size_t)a * c.N);
+		he = hipMemcpy(b + o_window, hw, sizeof(float) * (size_t)c.num_apod * c.N, hipMemcpyHostToDevice);
+		free(hw);
+		if(he != hipSuccess) { rc = hip_fail(he, "hipMemcpy(window)"); hipFree(e->arena); free(e); return rc; }
+	}
+	for(int i = 0; i < 7; i++) hipEventCreate(&e->ev[i]);
+	*out = e;
+	return FLACAMD_OK;
+}
+
+extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
+{
+	if(!e) return;
+	hipSetDevice(e->device);
+	for(int i = 0; i < 7; i++) if(e->ev[i]) hipEventDestroy(e->ev[i]);
+	if(e->arena) hipFree(e->arena);
+	if(e->d_pcm_stage) hipFree(e->d_pcm_stage);
+	if(e->d_out_stage) hipFree(e->d_out_stage);
+	if(e->d_fb_stage) hipFree(e->d_fb_stage);
+	free(e);
+}
+
+extern "C" void flacamd_encoder_set_timing(flacamd_encoder *e, int enabled) { if(e) e->timing = enabled; }
+
+extern "C" int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6])
+{
+	if(!e || !e->have_timing) return FLACAMD_E_INVALID_ARGUMENT;
+	for(int i = 0; i < 6; i++) ms[i] = e->last_ms[i];
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream)
+{
+	if(!e || !d_pcm || !d_out || nsamples == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && e->p.bits_per_sample > 16) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t N = e->cfg.N;
+	const uint64_t F64 = (nsamples + N - 1) / N;
+	if(!final_block && nsamples % N != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(F64 > e->max_frames) return FLACAMD_E_CAPACITY;
+	hipStream_t st = (hipStream_t)stream;
+	HIP_TRY(hipSetDevice(e->device));
+
+	FaCfg c = e->cfg;
+	c.pcm_format = (uint32_t)pcm_format;
+	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
+	c.last_n = (uint32_t)(nsamples - (F64 - 1) * N);
+	c.last_fractional = (final_block && c.last_n != N) ? 1u : 0u;
+	c.first_frame = first_frame_number; c.prev_assignment = prev_assignment;
+	e->last_F = c.F; e->last_G = c.G;
+
+	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
+	const bool tm = e->timing != 0;
+	if(tm) hipEventRecord(e->ev[0], st);
+	fa_launch_prep(d_pcm, &c, &e->work, st);
+	if(tm) hipEventRecord(e->ev[1], st);
+	if(c.max_lpc_order > 0) fa_launch_autoc(d_pcm, &c, &e->work, st);
+	if(tm) hipEventRecord(e->ev[2], st);
+	fa_launch_model(&c, &e->work, st);
+	if(tm) hipEventRecord(e->ev[3], st);
+	fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
+	if(tm) hipEventRecord(e->ev[4], st);
+	fa_launch_pack(d_pcm, &c, &e->work, st);
+	if(tm) hipEventRecord(e->ev[5], st);
+	fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
+	if(tm) hipEventRecord(e->ev[6], st);
+	HIP_TRY(hipGetLastError());
+
+	uint32_t status = 0; uint64_t total = 0;
+	HIP_TRY(hipMemcpyAsync(&status, e->work.status, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&total, e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if(tm) { for(int i = 0; i < 6; i++) hipEventElapsedTime(&e->last_ms[i], e->ev[i], e->ev[i+1]); e->have_timing = 1; }
+	if(h_total_bytes) *h_total_bytes = total;
+	if(status & 1u) return FLACAMD_E_FRAME_OVERFLOW;
+	if(status & 2u) return FLACAMD_E_CAPACITY;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	uint8_t *h_out, size_t out_cap, uint32_t *h_frame_bytes, uint64_t *h_total_bytes, uint32_t *h_last_assignment)
+{
+	if(!e || !h_pcm || !h_out || nsamples == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	HIP_TRY(hipSetDevice(e->device));
+	const size_t bytes_per = (pcm_format == FLACAMD_PCM_S16 ? 2u : 4u) * (size_t)e->p.channels;
+	const size_t pcm_bytes = (size_t)nsamples * bytes_per;
+	const uint64_t F = (nsamples + e->cfg.N - 1) / e->cfg.N;
+	if(F > e->max_frames) return FLACAMD_E_CAPACITY;
+	if(e->pcm_stage_bytes < pcm_bytes) {
+		if(e->d_pcm_stage) hipFree(e->d_pcm_stage);
+		e->d_pcm_stage = 0; e->pcm_stage_bytes = 0;
+		HIP_TRY(hipMalloc(&e->d_pcm_stage, pcm_bytes));
+		e->pcm_stage_bytes = pcm_bytes;
+	}
+	const size_t need_out = (size_t)F * e->cfg.slot_bytes;
+	if(e->out_stage_bytes < need_out) {
+		if(e->d_out_stage) hipFree(e->d_out_stage);
+		if(e->d_fb_stage) hipFree(e->d_fb_stage);
+		e->d_out_stage = 0; e->d_fb_stage = 0; e->out_stage_bytes = 0;
+		HIP_TRY(hipMalloc((void**)&e->d_out_stage, need_out));
+		HIP_TRY(hipMalloc((void**)&e->d_fb_stage, (size_t)e->max_frames * 4u));
+		e->out_stage_bytes = need_out;
+	}
+	HIP_TRY(hipMemcpy(e->d_pcm_stage, h_pcm, pcm_bytes, hipMemcpyHostToDevice));
+	uint64_t total = 0;
+	int rc = flacamd_encode_device(e, e->d_pcm_stage, pcm_format, nsamples, final_block, first_frame_number, prev_assignment,
+		e->d_out_stage, need_out, e->d_fb_stage, &total, 0);
+	if(rc != FLACAMD_OK) return rc;
+	if(total > out_cap) return FLACAMD_E_CAPACITY;
+	HIP_TRY(hipMemcpy(h_out, e->d_out_stage, total, hipMemcpyDeviceToHost));
+	if(h_frame_bytes) HIP_TRY(hipMemcpy(h_frame_bytes, e->d_fb_stage, (size_t)F * 4u, hipMemcpyDeviceToHost));
+	if(h_last_assignment) HIP_TRY(hipMemcpy(h_last_assignment, e->work.assignment + (F - 1), 4, hipMemcpyDeviceToHost));
+	if(h_total_bytes) *h_total_bytes = total;
+	return FLACAMD_OK;
+}
+
+extern "C" long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h_dst, size_t cap)
+{
+	if(!e || !h_dst || e->last_G == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(hipSetDevice(e->device) != hipSuccess) return FLACAMD_E_DEVICE;
+	const size_t G = e->last_G;
+	const void *src = 0; size_t bytes = 0;
+	switch(what) {
+	case 0: src = e->work.autoc; bytes = (size_t)e->cfg.num_apod * e->cfg.lag * G * 4u; break;
+	case 1: src = e->work.fixed_err; bytes = 5u * G * 8u; break;
+	case 2: break;
+	case 3: break;
+	case 4: src = e->work.wasted; bytes = G; break;
+	default: return FLACAMD_E_INVALID_ARGUMENT;
+	}
+	if(what == 2 || what == 3) {
+		// strided copy out of the winner records
+		FaWinner *tmp = (FaWinner*)malloc(G * sizeof(FaWinner));
+		if(!tmp) return FLACAMD_E_OUT_OF_MEMORY;
+		if(hipMemcpy(tmp, e->work.winner, G * sizeof(FaWinner), hipMemcpyDeviceToHost) != hipSuccess) { free(tmp); return FLACAMD_E_DEVICE; }
+		bytes = what == 2 ? G * 16u : G * 4u;
+		if(bytes > cap) { free(tmp); return FLACAMD_E_CAPACITY; }
+		for(size_t g = 0; g < G; g++) {
+			if(what == 2) memcpy((uint8_t*)h_dst + g * 16u, tmp[g].hdr, 16);
+			else memcpy((uint8_t*)h_dst + g * 4u, &tmp[g].hdr[1], 4);
+		}
+		free(tmp);
+		return (long)bytes;
+	}
+	// note: the layouts above are strided by the G of the LAST batch
+	if(bytes > cap) return FLACAMD_E_CAPACITY;
+	if(hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return FLACAMD_E_DEVICE;
+	return (long)bytes;
+}
+
+// ---- temporary: decoder / md5 entry points are implemented in decoder.hip / k_md5.hip
+#ifndef FA_HAVE_DECODER
+extern "C" int flacamd_md5_device(int, const void *, int, uint32_t, uint32_t, const uint64_t *, uint32_t, uint8_t *, void *) { return FLACAMD_E_UNSUPPORTED; }
+extern "C" int flacamd_decoder_create(flacamd_decoder **, int, uint32_t, uint32_t, uint32_t, uint32_t, size_t) { return FLACAMD_E_UNSUPPORTED; }
+extern "C" void flacamd_decoder_destroy(flacamd_decoder *) {}
+extern "C" int flacamd_decode_device(flacamd_decoder *, const void *, size_t, void *, int, uint64_t, uint64_t *, void *) { return FLACAMD_E_UNSUPPORTED; }
+extern "C" int flacamd_decode_host(flacamd_decoder *, const uint8_t *, size_t, void *, int, uint64_t, uint64_t *) { return FLACAMD_E_UNSUPPORTED; }
+#endif

@@ -1,0 +1,135 @@
+// Shared host/device definitions of the gfx950 FLAC frame engine.
+#pragma once
+#include <stdint.h>
+#include "../../include/flac_amd_engine.h"
+
+#define FA_MAX_FIXED_ORDER 4u
+#define FA_MIN_QLP_PRECISION 5u
+#define FA_MAX_QLP_PRECISION 15u
+#define FA_MAX_PARTS (1u << FLACAMD_MAX_PARTITION_ORDER)
+
+// subframe kinds (bitstream order of the type codes)
+enum { FA_SUB_CONSTANT = 0, FA_SUB_VERBATIM = 1, FA_SUB_FIXED = 2, FA_SUB_LPC = 3 };
+
+// Everything a kernel needs to know about the stream and the batch; passed by value
+// (lands in SGPRs).
+struct FaCfg {
+	uint32_t channels;        // 1..8
+	uint32_t bps;             // stream bits per sample
+	uint32_t rate;
+	uint32_t N;               // stream blocksize
+	uint32_t nsig;            // signals analysed per frame: 4 (L,R,M,S) for mid/side stereo, else channels
+	uint32_t midside;         // 1 when nsig == 4 comes from mid/side
+	uint32_t loose;           // loose mid/side
+	uint32_t loose_period;    // frames per decision period (stream_encoder.c:878-890)
+	uint32_t pcm_format;      // FLACAMD_PCM_*
+	uint32_t F;               // frames in this batch
+	uint32_t last_n;          // samples in the last frame of the batch
+	uint32_t last_fractional; // last frame is the short final block of the stream
+	uint32_t first_frame;     // frame number of frame 0 of the batch
+	uint32_t prev_assignment;
+	uint32_t max_lpc_order, qlp_precision, prec_search, exhaustive;
+	uint32_t min_po, max_po;  // as configured (before per-frame / per-order limiting)
+	uint32_t disable_constant, disable_fixed, disable_verbatim;
+	uint32_t num_apod;
+	uint32_t lag;             // max_lpc_order + 1
+	uint32_t max_cand;        // candidate slots per signal
+	uint32_t k_limit;         // 15, or 31 when stream bps > 16 (stream_encoder.c:3200)
+	uint32_t wide_fixed;      // 64-bit fixed-predictor error sums (stream_encoder.c:894)
+	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
+	uint32_t G;               // F * nsig
+};
+
+// Candidate header word written by the model kernel, read by the search kernel.
+//  [0]    kind: 0 fixed, 1 lpc
+//  [6:1]  order (0..32)
+//  [11:7] coefficient precision (lpc)
+//  [16:12] shift (lpc, 0..15)
+//  [21:17] suggested Rice parameter for partition order 0
+//  [22]   64-bit prediction sum (stream_encoder.c:3597-3603)
+#define FA_CAND_KIND(h)  ((h) & 1u)
+#define FA_CAND_ORDER(h) (((h) >> 1) & 63u)
+#define FA_CAND_PREC(h)  (((h) >> 7) & 31u)
+#define FA_CAND_SHIFT(h) (((h) >> 12) & 31u)
+#define FA_CAND_K(h)     (((h) >> 17) & 31u)
+#define FA_CAND_WIDE(h)  (((h) >> 22) & 1u)
+#define FA_CAND_PACK(kind, order, prec, shift, k, wide) \
+	((uint32_t)(kind) | ((uint32_t)(order) << 1) | ((uint32_t)(prec) << 7) | ((uint32_t)(shift) << 12) | ((uint32_t)(k) << 17) | ((uint32_t)(wide) << 22))
+
+// Winner record of one signal (search kernel -> pack kernel), array of structs.
+//  hdr[0]: [1:0] type  [7:2] order  [12:8] precision  [17:13] shift  [21:18] partition order
+//          [22] rice2  [27:23] wasted bits  [28] 64-bit prediction sum
+//  hdr[1]: estimated bits of the subframe (the value the reference compares)
+//  hdr[2]: subframe bits per sample
+//  hdr[3]: index of the winning candidate slot (0xffffffff for verbatim / constant)
+struct FaWinner {
+	uint32_t hdr[4];
+	int32_t  q[FLACAMD_MAX_LPC_ORDER];
+	uint8_t  k[FA_MAX_PARTS];
+};
+#define FA_WIN_TYPE(h)   ((h) & 3u)
+#define FA_WIN_ORDER(h)  (((h) >> 2) & 63u)
+#define FA_WIN_PREC(h)   (((h) >> 8) & 31u)
+#define FA_WIN_SHIFT(h)  (((h) >> 13) & 31u)
+#define FA_WIN_PO(h)     (((h) >> 18) & 15u)
+#define FA_WIN_RICE2(h)  (((h) >> 22) & 1u)
+#define FA_WIN_WASTED(h) (((h) >> 23) & 31u)
+#define FA_WIN_WIDE(h)   (((h) >> 28) & 1u)
+
+// Device workspace pointers of one encoder.
+struct FaWork {
+	// prep
+	uint8_t  *wasted;      // [G]
+	uint8_t  *is_const;    // [G]
+	uint64_t *fixed_err;   // [5][G]
+	// autocorrelation
+	float    *autoc;       // [num_apod][lag][G]
+	// model
+	uint32_t *ncand;       // [G]
+	uint32_t *cand_hdr;    // [max_cand][G]
+	int32_t  *cand_q;      // [max_cand][max_lpc_order][G]
+	// search
+	FaWinner *winner;      // [G]
+	// pack
+	uint8_t  *slots;       // [F][slot_bytes]
+	uint32_t *frame_bytes; // [F]
+	uint32_t *assignment;  // [F]
+	uint32_t *status;      // [1] nonzero = some frame overflowed its slot
+	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
+	const float *window;   // [num_apod][N]
+};
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+
+// number of samples in frame f of the batch
+__device__ __forceinline__ uint32_t fa_frame_len(const FaCfg &c, uint32_t f) { return (f + 1 == c.F) ? c.last_n : c.N; }
+
+// Sample `i` of channel `ch` of the wide-sample stream starting at batch sample 0.
+__device__ __forceinline__ int32_t fa_pcm(const void *pcm, uint32_t fmt, uint32_t channels, uint64_t wide, uint32_t ch)
+{
+	const uint64_t idx = wide * channels + ch;
+	return fmt == FLACAMD_PCM_S16 ? (int32_t)((const int16_t*)pcm)[idx] : ((const int32_t*)pcm)[idx];
+}
+
+// Signal `s` of a frame at wide-sample index `wide`, before wasted-bit removal.
+// Mid/side as stream_encoder.c:2051-2058: mid = (l + r) >> 1 (arithmetic), side = l - r.
+__device__ __forceinline__ int32_t fa_signal(const void *pcm, const FaCfg &c, uint32_t s, uint64_t wide)
+{
+	if(c.midside) {
+		if(c.pcm_format == FLACAMD_PCM_S16) {
+			const uint32_t lr = ((const uint32_t*)pcm)[wide];
+			const int32_t l = (int16_t)(lr & 0xffffu), r = (int32_t)lr >> 16;
+			return s == 0 ? l : s == 1 ? r : s == 2 ? ((l + r) >> 1) : (l - r);
+		}
+		else {
+			const int2 lr = ((const int2*)pcm)[wide];
+			const int32_t l = lr.x, r = lr.y;
+			return s == 0 ? l : s == 1 ? r : s == 2 ? (int32_t)((uint32_t)l + (uint32_t)r) >> 1 : (int32_t)((uint32_t)l - (uint32_t)r);
+		}
+	}
+	return fa_pcm(pcm, c.pcm_format, c.channels, wide, s);
+}
+
+__device__ __forceinline__ uint32_t fa_ilog2(uint32_t v) { return 31u - (uint32_t)__clz((int)v); } // v > 0
+#endif

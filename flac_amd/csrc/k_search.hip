@@ -1,0 +1,375 @@
+// Stage 3 of the encoder: evaluate every residual-coding candidate of a signal and keep
+// the one the reference would keep.
+//
+// Replaces, for one signal of one frame:
+//   FLAC__fixed_compute_residual                       fixed.c:352-393
+//   FLAC__lpc_compute_residual_from_qlp_coefficients   lpc.c:265-529 (32-bit wrapping sum)
+//   ..._from_qlp_coefficients_wide                     lpc.c:531-791 (64-bit sum)
+//   precompute_partition_info_sums_                    stream_encoder.c:3779-3847
+//   set_partitioned_rice_ / count_rice_bits_in_partition_  :3923-4111
+//   find_best_partition_order_                         :3671-3766
+//   the keep-best chain of process_subframe_           :3205-3239, :3288-3291, :3376-3381, :3393
+//
+// One 256-thread workgroup per (frame, signal).  The signal is staged once into LDS
+// (padded so that 16-sample register windows load without bank conflicts); each thread
+// keeps 16 samples + 12 of history in registers and evaluates ALL candidates on them
+// (coefficients are wave-uniform: scalar loads), so the signal is read from HBM/L2 once
+// per workgroup, not once per candidate as on the CPU.  |residual| sums go to LDS
+// per finest-level partition (one LDS atomic per thread per candidate), the Rice parameter
+// / partition-order search runs over (candidate, order, partition) items in parallel, and
+// an ordered arg-min (estimate, candidate index) reproduces the reference's strict-'<'
+// keep-first tie-breaking.  Nothing but the winner record leaves the CU.
+//
+// This is integer work bound by VALU issue, not by HBM: ~(order+5) lane-ops per sample
+// per LPC candidate.
+#include "engine_types.h"
+
+#define CH 16          // samples per register chunk
+#define HIST 12        // history kept in registers: orders above 12 take the generic path
+
+// LDS index of signal sample i (i >= -32): one pad word per 16 so that lanes reading
+// windows at a 16-sample stride hit distinct banks.
+__device__ __forceinline__ uint32_t xs_idx(int32_t i) { const uint32_t u = (uint32_t)(i + 32); return u + (u >> 4); }
+
+__device__ __forceinline__ uint32_t abs_u32(int32_t r) { return (uint32_t)(r < 0 ? 0u - (uint32_t)r : (uint32_t)r); }
+
+enum { MAC_I24 = 0, MAC_I32 = 1, MAC_WIDE = 2 };
+
+// |residual| sums of one 16-sample chunk for an order-P predictor.  `head` collects the
+// first P samples of the chunk (they are warm-up samples, not residuals, when the chunk
+// is the first of the frame), `tail` the rest.
+template<int P, int MODE, typename SUM>
+__device__ __forceinline__ void lpc_chunk(const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, SUM &head, SUM &tail)
+{
+	SUM h = 0, t = 0;
+#pragma unroll
+	for(int s = 0; s < CH; s++) {
+		int32_t pred;
+		if(MODE == MAC_WIDE) {
+			long long acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+			pred = (int32_t)(acc >> shift);
+		}
+		else if(MODE == MAC_I24) {
+			int32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc = __mul24(q[j], xw[HIST + s - 1 - j]) + acc; // low 32 bits of the sum: same wrap as lpc.c:296
+			pred = acc >> shift;
+		}
+		else {
+			uint32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
+			pred = (int32_t)acc >> shift;
+		}
+		const uint32_t m = abs_u32((int32_t)((uint32_t)xw[HIST + s] - (uint32_t)pred));
+		if(s < P) h += m; else t += m;
+	}
+	head = h; tail = t;
+}
+
+template<int MODE, typename SUM>
+__device__ __forceinline__ void lpc_chunk_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, SUM &head, SUM &tail)
+{
+	switch(order) {
+	case 1: lpc_chunk<1, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 2: lpc_chunk<2, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 3: lpc_chunk<3, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 4: lpc_chunk<4, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 5: lpc_chunk<5, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 6: lpc_chunk<6, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 7: lpc_chunk<7, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 8: lpc_chunk<8, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 9: lpc_chunk<9, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 10: lpc_chunk<10, MODE, SUM>(xw, q, shift, head, tail); break;
+	case 11: lpc_chunk<11, MODE, SUM>(xw, q, shift, head, tail); break;
+	default: lpc_chunk<12, MODE, SUM>(xw, q, shift, head, tail); break;
+	}
+}
+
+// k-th difference (fixed.c:352-393) of the chunk, 32-bit wrapping
+template<int K, typename SUM>
+__device__ __forceinline__ void fixed_chunk(const int32_t (&xw)[HIST + CH], SUM &head, SUM &tail)
+{
+	SUM h = 0, t = 0;
+#pragma unroll
+	for(int s = 0; s < CH; s++) {
+		const uint32_t a = (uint32_t)xw[HIST + s], b = (uint32_t)xw[HIST + s - 1], c = (uint32_t)xw[HIST + s - 2], d = (uint32_t)xw[HIST + s - 3], e = (uint32_t)xw[HIST + s - 4];
+		uint32_t r;
+		if(K == 0) r = a; else if(K == 1) r = a - b; else if(K == 2) r = a - 2u*b + c; else if(K == 3) r = a - 3u*b + 3u*c - d; else r = a - 4u*b + 6u*c - 4u*d + e;
+		const uint32_t m = abs_u32((int32_t)r);
+		if(s < K) h += m; else t += m;
+	}
+	head = h; tail = t;
+}
+
+// format.c:548-561
+__device__ __forceinline__ uint32_t limit_po(uint32_t limit, uint32_t blocksize, uint32_t order)
+{
+	while(limit > 0 && (blocksize >> limit) <= order) limit--;
+	return limit;
+}
+
+struct SearchShared {
+	uint32_t best_est, best_cand, best_po, have_best;
+	uint32_t rice2, group_won;
+};
+
+template<typename SUM>
+__global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	__shared__ SearchShared sh;
+
+	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
+	const uint32_t n = fa_frame_len(c, f);
+	const uint64_t base = (uint64_t)f * c.N;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t wasted = w.wasted[g];
+	const uint32_t bps = c.bps - wasted + ((c.midside && s == 3u) ? 1u : 0u);
+	const uint32_t ncand = w.ncand[g];
+
+	// frame-level partition order range (stream_encoder.c:2934-2941)
+	uint32_t maxpo_f;
+	if(f + 1 == c.F && c.last_fractional) maxpo_f = 0;
+	else { const uint32_t tz = (uint32_t)__ffs((int)n) - 1u; maxpo_f = tz < c.max_po ? tz : c.max_po; }
+	const uint32_t minpo_f = c.min_po < maxpo_f ? c.min_po : maxpo_f;
+	const uint32_t parts0 = 1u << maxpo_f, dps0 = n >> maxpo_f;
+	const bool fast = ((n & (CH - 1)) == 0) && ((dps0 & (CH - 1)) == 0);
+
+	// LDS carve-up
+	const uint32_t xs_words = ((c.N + 32u) * 17u) / 16u + 17u;
+	int32_t *xs = (int32_t*)lds_raw;
+	unsigned long long *psum = (unsigned long long*)(lds_raw + (((size_t)xs_words * 4u + 15u) & ~(size_t)15u)); // [cg][FA_MAX_PARTS rows trimmed to parts_cap]
+	const uint32_t parts_cap = 1u << (c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER);
+	uint32_t *lbits = (uint32_t*)(psum + (size_t)cg * parts_cap);                 // [cg][16]
+	unsigned long long *ckey = (unsigned long long*)(lbits + (size_t)cg * 16u);    // [cg]
+	uint32_t *cpo = (uint32_t*)(ckey + cg);                                        // [cg]
+	uint8_t *kbuf = (uint8_t*)(cpo + cg);                                          // [cg][2*parts_cap]
+	uint8_t *best_k = kbuf + (size_t)cg * 2u * parts_cap;                          // [parts_cap]
+
+	// ---- stage the signal: xs[-32..-1] = 0, xs[0..n) = signal >> wasted, zero up to the next chunk boundary
+	if(tid == 0) { sh.have_best = 0; sh.best_est = 0; sh.best_cand = 0xffffffffu; sh.best_po = 0; sh.rice2 = 0; }
+	if(tid < 32) xs[xs_idx((int32_t)tid - 32)] = 0;
+	{
+		const uint32_t nup = (n + CH - 1u) & ~(CH - 1u);
+		for(uint32_t i = tid; i < nup; i += 256) xs[xs_idx((int32_t)i)] = (i < n) ? (fa_signal(pcm, c, s, base + i) >> wasted) : 0;
+	}
+	__syncthreads();
+
+	const uint32_t qrows = c.max_lpc_order ? c.max_lpc_order : 1u;
+
+	for(uint32_t cb = 0; cb < ncand; cb += cg) {
+		const uint32_t gn = (ncand - cb) < cg ? (ncand - cb) : cg;
+		for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * parts_cap + (t % parts0)] = 0;
+		for(uint32_t t = tid; t < gn * 16u; t += 256) lbits[t] = 0;
+		__syncthreads();
+
+		// ---- |residual| sums per finest partition
+		if(fast) {
+			const uint32_t cpp = dps0 / CH; // chunks per finest partition
+			for(uint32_t chunk = tid; chunk * CH < n; chunk += 256) {
+				int32_t xw[HIST + CH];
+#pragma unroll
+				for(int j = 0; j < HIST + CH; j++) xw[j] = xs[xs_idx((int32_t)(chunk * CH) - HIST + j)];
+				const uint32_t part = chunk / cpp;
+				for(uint32_t ci = 0; ci < gn; ci++) {
+					const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+					const uint32_t order = FA_CAND_ORDER(hdr);
+					SUM head = 0, tail = 0;
+					if(FA_CAND_KIND(hdr) == 0) {
+						switch(order) {
+						case 0: fixed_chunk<0, SUM>(xw, head, tail); break;
+						case 1: fixed_chunk<1, SUM>(xw, head, tail); break;
+						case 2: fixed_chunk<2, SUM>(xw, head, tail); break;
+						case 3: fixed_chunk<3, SUM>(xw, head, tail); break;
+						default: fixed_chunk<4, SUM>(xw, head, tail); break;
+						}
+					}
+					else if(order <= HIST) {
+						int32_t q[HIST];
+#pragma unroll
+						for(int j = 0; j < HIST; j++) q[j] = ((uint32_t)j < order) ? w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] : 0;
+						const uint32_t shift = FA_CAND_SHIFT(hdr);
+						if(FA_CAND_WIDE(hdr)) lpc_chunk_dispatch<MAC_WIDE, SUM>(order, xw, q, shift, head, tail);
+						else if(bps <= 24) lpc_chunk_dispatch<MAC_I24, SUM>(order, xw, q, shift, head, tail);
+						else lpc_chunk_dispatch<MAC_I32, SUM>(order, xw, q, shift, head, tail);
+					}
+					else continue; // high orders: generic pass below
+					const SUM v = tail + (chunk == 0 ? (SUM)0 : head);
+					if(sizeof(SUM) == 4) atomicAdd((uint32_t*)&psum[(size_t)ci * parts_cap + part], (uint32_t)v);
+					else atomicAdd(&psum[(size_t)ci * parts_cap + part], (unsigned long long)v);
+				}
+			}
+		}
+		// generic per-sample pass: any frame length / partition length, and orders above HIST
+		for(uint32_t ci = 0; ci < gn; ci++) {
+			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+			const uint32_t order = FA_CAND_ORDER(hdr), kind = FA_CAND_KIND(hdr);
+			if(fast && (kind == 0 || order <= HIST)) continue;
+			const uint32_t shift = FA_CAND_SHIFT(hdr), wide = FA_CAND_WIDE(hdr);
+			for(uint32_t i = tid + order; i < n; i += 256) {
+				int32_t r;
+				if(kind == 0) {
+					const uint32_t a = (uint32_t)xs[xs_idx((int32_t)i)], b = (uint32_t)xs[xs_idx((int32_t)i - 1)], cc = (uint32_t)xs[xs_idx((int32_t)i - 2)],
+					               d = (uint32_t)xs[xs_idx((int32_t)i - 3)], e = (uint32_t)xs[xs_idx((int32_t)i - 4)];
+					r = (int32_t)(order == 0 ? a : order == 1 ? a - b : order == 2 ? a - 2u*b + cc : order == 3 ? a - 3u*b + 3u*cc - d : a - 4u*b + 6u*cc - 4u*d + e);
+				}
+				else {
+					int32_t pred;
+					if(wide) {
+						long long acc = 0;
+						for(uint32_t j = 0; j < order; j++) acc += (long long)w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] * (long long)xs[xs_idx((int32_t)(i - 1u - j))];
+						pred = (int32_t)(acc >> shift);
+					}
+					else {
+						uint32_t acc = 0;
+						for(uint32_t j = 0; j < order; j++) acc += (uint32_t)w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] * (uint32_t)xs[xs_idx((int32_t)(i - 1u - j))];
+						pred = (int32_t)acc >> shift;
+					}
+					r = (int32_t)((uint32_t)xs[xs_idx((int32_t)i)] - (uint32_t)pred);
+				}
+				atomicAdd(&psum[(size_t)ci * parts_cap + i / dps0], (unsigned long long)abs_u32(r));
+			}
+		}
+		__syncthreads();
+
+		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition)
+		const uint32_t per = 2u * parts0;
+		for(uint32_t t = tid; t < gn * per; t += 256) {
+			const uint32_t ci = t / per, idx = t - ci * per;
+			if(idx >= per - 1u) continue;
+			// idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
+			uint32_t lvl = 0, off = 0, cnt = parts0;
+			while(idx >= off + cnt) { off += cnt; cnt >>= 1; lvl++; }
+			const uint32_t po = maxpo_f - lvl, p = idx - off;
+			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+			const uint32_t order = FA_CAND_ORDER(hdr);
+			const uint32_t maxpo_c = limit_po(maxpo_f, n, order);
+			const uint32_t minpo_c = minpo_f < maxpo_c ? minpo_f : maxpo_c;
+			if(po > maxpo_c || po < minpo_c) continue;
+			// sum of the finest-level sums below this partition; the reference's accumulator at the
+			// candidate's own finest order wraps at 32 bits when ilog2(partition length) + bps < 32
+			const bool narrow_c = fa_ilog2(n >> maxpo_c) + bps < 32u;
+			const uint32_t group = 1u << (maxpo_f - maxpo_c), mids = 1u << (maxpo_c - po);
+			unsigned long long sum = 0;
+			for(uint32_t a = 0; a < mids; a++) {
+				unsigned long long sub = 0;
+				for(uint32_t b = 0; b < group; b++) sub += psum[(size_t)ci * parts_cap + (p * mids + a) * group + b];
+				if(narrow_c) sub &= 0xffffffffull;
+				sum += sub;
+			}
+			const uint32_t nsamp = (n >> po) - (p == 0 ? order : 0u);
+			uint32_t k;
+			if(po == 0) k = FA_CAND_K(hdr);   // stream_encoder.c:3982-4029
+			else {                             // :4052 smallest k with nsamp << k >= sum
+				k = 0;
+				if(sum > (unsigned long long)nsamp) {
+					const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)sum), bl_n = 32u - (uint32_t)__clz((int)nsamp);
+					k = bl_s - bl_n;
+					if(((unsigned long long)nsamp << k) < sum) k++;
+				}
+				if(k >= c.k_limit) k = c.k_limit - 1u;
+			}
+			// :3929-3937, unsigned 32-bit arithmetic
+			const uint32_t est = 4u + (1u + k) * nsamp + (k ? (uint32_t)(sum >> (k - 1u)) : (uint32_t)(sum << 1)) - (nsamp >> 1);
+			kbuf[(size_t)ci * 2u * parts_cap + idx] = (uint8_t)k;
+			atomicAdd(&lbits[ci * 16u + lvl], est);
+		}
+		__syncthreads();
+
+		// ---- best partition order of each candidate (searched max -> min, strict '<'), subframe estimate
+		if(tid < gn) {
+			const uint32_t ci = tid;
+			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+			const uint32_t order = FA_CAND_ORDER(hdr);
+			const uint32_t maxpo_c = limit_po(maxpo_f, n, order);
+			const uint32_t minpo_c = minpo_f < maxpo_c ? minpo_f : maxpo_c;
+			uint32_t best = 0, bestpo = 0; bool have = false;
+			for(int po = (int)maxpo_c; po >= (int)minpo_c; po--) {
+				const uint32_t b = 6u + lbits[ci * 16u + (maxpo_f - (uint32_t)po)];
+				if(!have || b < best) { best = b; bestpo = (uint32_t)po; have = true; }
+			}
+			uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
+			if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
+			ckey[ci] = ((unsigned long long)est << 32) | (unsigned long long)(cb + ci);
+			cpo[ci] = bestpo;
+		}
+		__syncthreads();
+		if(tid == 0) {
+			unsigned long long bk = ~0ull; uint32_t bi = 0;
+			for(uint32_t ci = 0; ci < gn; ci++) if(ckey[ci] < bk) { bk = ckey[ci]; bi = ci; }
+			const uint32_t est = (uint32_t)(bk >> 32);
+			// earlier groups hold earlier candidates: replace only when strictly smaller
+			sh.group_won = 0;
+			if(!sh.have_best || est < sh.best_est) { sh.have_best = 1; sh.best_est = est; sh.best_cand = cb + bi; sh.best_po = cpo[bi]; sh.group_won = 1; }
+		}
+		__syncthreads();
+		if(sh.group_won) {
+			const uint32_t ci = sh.best_cand - cb, po = sh.best_po, lvl = maxpo_f - po;
+			uint32_t off = 0, cnt = parts0;
+			for(uint32_t l = 0; l < lvl; l++) { off += cnt; cnt >>= 1; }
+			for(uint32_t p = tid; p < (1u << po); p += 256) best_k[p] = kbuf[(size_t)ci * 2u * parts_cap + off + p];
+		}
+		__syncthreads();
+	}
+
+	// ---- final choice against verbatim / constant (stream_encoder.c:3205-3239, :3393-3396)
+	const uint32_t verb_bits = 8u + wasted + n * bps;
+	uint32_t base_bits = (c.disable_verbatim && n >= FA_MAX_FIXED_ORDER) ? 0xffffffffu : verb_bits;
+	uint32_t type = FA_SUB_VERBATIM, est = base_bits;
+	const bool constant = (!c.disable_constant) && n >= FA_MAX_FIXED_ORDER && w.is_const[g];
+	if(constant) { const uint32_t cbits = 8u + wasted + bps; if(cbits < est) { type = FA_SUB_CONSTANT; est = cbits; } }
+	bool use_cand = false;
+	if(sh.have_best && ncand > 0 && sh.best_est < est) { use_cand = true; est = sh.best_est; }
+	if(est == 0xffffffffu) { type = FA_SUB_VERBATIM; est = verb_bits; }
+
+	FaWinner *win = &w.winner[g];
+	if(use_cand) {
+		const uint32_t bc = sh.best_cand;
+		const uint32_t hdr = w.cand_hdr[(size_t)bc * c.G + g];
+		const uint32_t order = FA_CAND_ORDER(hdr), po = sh.best_po;
+		bool big = false;
+		for(uint32_t p = tid; p < (1u << po); p += 256) { const uint8_t k = best_k[p]; win->k[p] = k; big |= (k >= 15); }
+		if(big) atomicOr(&sh.rice2, 1u);
+		if(tid < FLACAMD_MAX_LPC_ORDER) win->q[tid] = (FA_CAND_KIND(hdr) && tid < order) ? w.cand_q[((size_t)bc * qrows + tid) * c.G + g] : 0;
+		__syncthreads();
+		if(tid == 0) {
+			const uint32_t ty = FA_CAND_KIND(hdr) ? FA_SUB_LPC : FA_SUB_FIXED;
+			win->hdr[0] = ty | (order << 2) | (FA_CAND_PREC(hdr) << 8) | (FA_CAND_SHIFT(hdr) << 13) | (po << 18) | (sh.rice2 << 22) | (wasted << 23) | (FA_CAND_WIDE(hdr) << 28);
+			win->hdr[1] = est; win->hdr[2] = bps; win->hdr[3] = bc;
+		}
+	}
+	else if(tid == 0) {
+		win->hdr[0] = type | (wasted << 23);
+		win->hdr[1] = est; win->hdr[2] = bps; win->hdr[3] = 0xffffffffu;
+	}
+}
+
+extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
+{
+	const size_t xs_words = ((size_t)(c->N + 32u) * 17u) / 16u + 17u;
+	const size_t parts_cap = (size_t)1 << (c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER);
+	size_t b = (xs_words * 4u + 15u) & ~(size_t)15u;
+	b += (size_t)cg * parts_cap * 8u;  // psum
+	b += (size_t)cg * 16u * 4u;        // lbits
+	b += (size_t)cg * 8u;              // ckey
+	b += (size_t)cg * 4u;              // cpo
+	b += (size_t)cg * 2u * parts_cap;  // kbuf
+	b += parts_cap;                    // best_k
+	return (b + 15u) & ~(size_t)15u;
+}
+
+extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st)
+{
+	const size_t lds = fa_search_lds_bytes(c, cg);
+	if(sum64) {
+		hipFuncSetAttribute((const void*)fa_search_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_search_kernel<unsigned long long>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w, cg);
+	}
+	else {
+		hipFuncSetAttribute((const void*)fa_search_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_search_kernel<uint32_t>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w, cg);
+	}
+}

@@ -1,0 +1,192 @@
+"""ctypes binding of libflacamd.so (include/flac_amd_engine.h).
+
+The library is the product: HIP kernels for gfx950 behind a plain C ABI.  This module only
+marshals arguments; it contains no arithmetic of its own and no CPU fallback - if the shared
+library or a HIP device is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflacamd.so")
+
+PCM_S32, PCM_S16 = 0, 1
+
+WINDOWS = ["bartlett", "bartlett_hann", "blackman", "blackman_harris_4term_92db", "connes", "flattop", "gauss",
+           "hamming", "hann", "kaiser_bessel", "nuttall", "rectangle", "triangle", "tukey", "welch"]
+
+ERRORS = {-1: "invalid argument", -2: "outside the engine limits", -3: "no HIP device", -4: "out of device memory",
+          -5: "HIP call failed", -6: "capacity too small", -7: "frame exceeded its slot", -8: "bad stream"}
+
+
+class Params(C.Structure):
+    """flacamd_params"""
+    _fields_ = [(n, C.c_uint32) for n in (
+        "channels", "bits_per_sample", "sample_rate", "blocksize", "do_mid_side", "loose_mid_side",
+        "max_lpc_order", "qlp_coeff_precision", "do_qlp_coeff_prec_search", "do_exhaustive_model_search",
+        "min_residual_partition_order", "max_residual_partition_order",
+        "disable_constant", "disable_fixed", "disable_verbatim", "num_apodizations")] + [
+        ("apod_type", C.c_uint32 * 32), ("apod_param", C.c_float * 32)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (where, ERRORS.get(code, "?"), code, (" - " + detail) if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Load libflacamd.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s not built; run __graft_entry__.build()" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+        L.flacamd_params_preset.argtypes = [C.POINTER(Params), C.c_uint]
+        L.flacamd_params_preset.restype = None
+        L.flacamd_params_resolve.argtypes = [C.POINTER(Params)]
+        L.flacamd_window.argtypes = [u32, C.c_float, C.c_int32, vp]
+        L.flacamd_window.restype = None
+        L.flacamd_encoder_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Params), u32]
+        L.flacamd_encoder_destroy.argtypes = [vp]
+        L.flacamd_encoder_destroy.restype = None
+        L.flacamd_encoder_params.argtypes = [vp]
+        L.flacamd_encoder_params.restype = C.POINTER(Params)
+        L.flacamd_encoder_max_output_bytes.argtypes = [vp, u32]
+        L.flacamd_encoder_max_output_bytes.restype = sz
+        L.flacamd_encode_device.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), vp]
+        L.flacamd_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), C.POINTER(u32)]
+        L.flacamd_encoder_debug_read.argtypes = [vp, C.c_int, vp, sz]
+        L.flacamd_encoder_debug_read.restype = C.c_long
+        L.flacamd_encoder_set_timing.argtypes = [vp, C.c_int]
+        L.flacamd_encoder_set_timing.restype = None
+        L.flacamd_encoder_last_timing.argtypes = [vp, C.POINTER(C.c_float * 6)]
+        L.flacamd_md5_device.argtypes = [C.c_int, vp, C.c_int, u32, u32, vp, u32, vp, vp]
+        L.flacamd_decoder_create.argtypes = [C.POINTER(vp), C.c_int, u32, u32, u32, u32, sz]
+        L.flacamd_decoder_destroy.argtypes = [vp]
+        L.flacamd_decoder_destroy.restype = None
+        L.flacamd_decode_device.argtypes = [vp, vp, sz, vp, C.c_int, u64, vp, vp]
+        L.flacamd_decode_host.argtypes = [vp, vp, sz, vp, C.c_int, u64, vp]
+        L.flacamd_strerror.argtypes = [C.c_int]
+        L.flacamd_strerror.restype = C.c_char_p
+        L.flacamd_last_error.restype = C.c_char_p
+        L.flacamd_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise EngineError(rc, where, lib().flacamd_last_error().decode(errors="replace"))
+
+
+def make_params(channels, bits_per_sample, sample_rate, level=8, blocksize=0, apodization=None, **over):
+    """Build a Params for a compression level (the reference's -0..-8) with field overrides.
+    apodization: list of (window name, parameter)."""
+    p = Params()
+    p.channels, p.bits_per_sample, p.sample_rate, p.blocksize = channels, bits_per_sample, sample_rate, blocksize
+    lib().flacamd_params_preset(C.byref(p), level)
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    if apodization:
+        p.num_apodizations = len(apodization)
+        for i, (name, prm) in enumerate(apodization):
+            p.apod_type[i] = WINDOWS.index(name)
+            p.apod_param[i] = prm
+    return p
+
+
+def window(name, param, length):
+    w = np.empty(length, dtype=np.float32)
+    lib().flacamd_window(WINDOWS.index(name), param, length, w.ctypes.data)
+    return w
+
+
+class Encoder:
+    """One stream's encoder on one GPU (flacamd_encoder)."""
+
+    def __init__(self, params, max_frames, device=0):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        _check(self._lib.flacamd_encoder_create(C.byref(self._h), device, C.byref(params), max_frames), "flacamd_encoder_create")
+        self.params = self._lib.flacamd_encoder_params(self._h).contents
+        self.blocksize = int(self.params.blocksize)
+        self.channels = int(self.params.channels)
+        self.max_frames = max_frames
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.flacamd_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def max_output_bytes(self, nframes):
+        return int(self._lib.flacamd_encoder_max_output_bytes(self._h, nframes))
+
+    def set_timing(self, on=True):
+        self._lib.flacamd_encoder_set_timing(self._h, 1 if on else 0)
+
+    def last_timing(self):
+        ms = (C.c_float * 6)()
+        _check(self._lib.flacamd_encoder_last_timing(self._h, C.byref(ms)), "flacamd_encoder_last_timing")
+        return dict(zip(("prep", "autoc", "model", "search", "pack", "gather"), [float(v) for v in ms]))
+
+    def encode_host(self, pcm, final=True, first_frame=0, prev_assignment=0):
+        """pcm: numpy (samples, channels) int32 or int16. Returns (list of frame bytes, last assignment)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype == np.int16:
+            fmt = PCM_S16
+        elif pcm.dtype == np.int32:
+            fmt = PCM_S32
+        else:
+            raise TypeError("pcm must be int16 or int32")
+        n = pcm.shape[0]
+        if pcm.ndim != 2 or pcm.shape[1] != self.channels:
+            raise ValueError("pcm shape")
+        F = (n + self.blocksize - 1) // self.blocksize
+        cap = self.max_output_bytes(F)
+        out = np.empty(cap, dtype=np.uint8)
+        fb = np.zeros(F, dtype=np.uint32)
+        total = C.c_uint64(0)
+        last = C.c_uint32(0)
+        _check(self._lib.flacamd_encode_host(self._h, pcm.ctypes.data, fmt, n, 1 if final else 0, first_frame, prev_assignment,
+                                              out.ctypes.data, cap, fb.ctypes.data, C.byref(total), C.byref(last)), "flacamd_encode_host")
+        frames, off = [], 0
+        for s in fb:
+            frames.append(bytes(out[off:off + int(s)]))
+            off += int(s)
+        assert off == total.value
+        return frames, int(last.value)
+
+    def encode_device(self, d_pcm_ptr, fmt, nsamples, d_out_ptr, out_cap, d_frame_bytes_ptr, final=True, first_frame=0,
+                      prev_assignment=0, stream=None):
+        """Raw device-pointer entry (ints). Returns total bytes."""
+        total = C.c_uint64(0)
+        _check(self._lib.flacamd_encode_device(self._h, d_pcm_ptr, fmt, nsamples, 1 if final else 0, first_frame, prev_assignment,
+                                                d_out_ptr, out_cap, d_frame_bytes_ptr, C.byref(total), stream), "flacamd_encode_device")
+        return int(total.value)
+
+    def debug(self, what, dtype, count):
+        buf = np.empty(count, dtype=dtype)
+        got = self._lib.flacamd_encoder_debug_read(self._h, what, buf.ctypes.data, buf.nbytes)
+        if got < 0:
+            raise EngineError(got, "flacamd_encoder_debug_read")
+        return buf[: got // buf.itemsize]
+
+
+def device_count():
+    return int(lib().flacamd_device_count())

@@ -1,0 +1,170 @@
+/* C ABI of the MI355X (gfx950) FLAC frame engine.
+ *
+ * This is the drop-in boundary: a batch of whole, independent frames goes in, packed
+ * FLAC frames and their sizes come out.  It replaces, one level above the reference's
+ * per-call function pointers (stream_encoder.c:378-386), the body
+ *     process_frame_ -> process_subframes_ -> process_subframe_ -> evaluate_*_subframe_
+ *     -> find_best_partition_order_ -> FLAC__frame_add_header / add_subframe_ -> CRC-16
+ * (stream_encoder.c:2866-3167, :3169-3402, :3475-3766; stream_encoder_framing.c:219-553)
+ * for encode, and read_frame_ -> read_subframe_* -> read_residual_partitioned_rice_ ->
+ * restore_signal -> channel decorrelation (stream_decoder.c:2002-2145, :2456-2777) for
+ * decode.  The host-side libFLAC-style object (flac_amd/csrc/stream_encoder_shim.c)
+ * queues blocks, calls these entry points and replays write_frame_ in stream order.
+ *
+ * Plain C: pointers and sizes only, no HIP or torch types.  Device pointers are passed
+ * as void* / const void*; streams as void* (a hipStream_t, or NULL for the default stream).
+ * Every function returns 0 on success or a negative FLACAMD_E_* code; nothing falls back
+ * to a CPU path.
+ */
+#ifndef FLAC_AMD_ENGINE_H
+#define FLAC_AMD_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACAMD_MAX_CHANNELS 8
+#define FLACAMD_MAX_LPC_ORDER 32
+#define FLACAMD_MAX_APODIZATIONS 32
+#define FLACAMD_MAX_BLOCKSIZE 16384      /* engine limit (LDS-resident signals) */
+#define FLACAMD_MAX_PARTITION_ORDER 8    /* engine limit; 8 is also the subset limit */
+
+/* error codes */
+#define FLACAMD_OK 0
+#define FLACAMD_E_INVALID_ARGUMENT (-1)
+#define FLACAMD_E_UNSUPPORTED (-2)       /* legal for the reference, outside the engine limits above */
+#define FLACAMD_E_NO_DEVICE (-3)
+#define FLACAMD_E_OUT_OF_MEMORY (-4)
+#define FLACAMD_E_DEVICE (-5)            /* a HIP call failed; see flacamd_last_error() */
+#define FLACAMD_E_CAPACITY (-6)          /* output buffer / batch capacity too small */
+#define FLACAMD_E_FRAME_OVERFLOW (-7)    /* a frame exceeded its slot (pathological residuals) */
+#define FLACAMD_E_BAD_STREAM (-8)        /* decoder: sync / CRC / reserved-field failure */
+
+/* Window kinds in the order of the reference's set_apodization parser
+ * (stream_encoder.c:1546-1585). */
+enum {
+	FLACAMD_WIN_BARTLETT = 0, FLACAMD_WIN_BARTLETT_HANN, FLACAMD_WIN_BLACKMAN, FLACAMD_WIN_BLACKMAN_HARRIS_4TERM,
+	FLACAMD_WIN_CONNES, FLACAMD_WIN_FLATTOP, FLACAMD_WIN_GAUSS, FLACAMD_WIN_HAMMING, FLACAMD_WIN_HANN,
+	FLACAMD_WIN_KAISER_BESSEL, FLACAMD_WIN_NUTTALL, FLACAMD_WIN_RECTANGLE, FLACAMD_WIN_TRIANGLE, FLACAMD_WIN_TUKEY,
+	FLACAMD_WIN_WELCH
+};
+
+/* PCM layouts accepted by the encoder / produced by the decoder (always interleaved by
+ * channel, one "wide sample" = one sample of every channel). */
+enum {
+	FLACAMD_PCM_S32 = 0,  /* int32 per sample, right-justified: what process_interleaved takes (stream_encoder.h:1760) */
+	FLACAMD_PCM_S16 = 1   /* int16 per sample (streams with bits_per_sample <= 16) */
+};
+
+/* The analysis settings of one stream: the fields of FLAC__StreamEncoderProtected that the
+ * frame path reads (include/protected/stream_encoder.h:78-108). Zero means "default" for
+ * blocksize and qlp_coeff_precision exactly as in init_stream_internal_
+ * (stream_encoder.c:686-735). */
+typedef struct {
+	uint32_t channels, bits_per_sample, sample_rate, blocksize;
+	uint32_t do_mid_side, loose_mid_side;
+	uint32_t max_lpc_order, qlp_coeff_precision, do_qlp_coeff_prec_search;
+	uint32_t do_exhaustive_model_search;
+	uint32_t min_residual_partition_order, max_residual_partition_order;
+	uint32_t disable_constant, disable_fixed, disable_verbatim; /* stream_encoder.c:1747-1778 */
+	uint32_t num_apodizations;
+	uint32_t apod_type[FLACAMD_MAX_APODIZATIONS];
+	float    apod_param[FLACAMD_MAX_APODIZATIONS]; /* tukey p / gauss stddev */
+} flacamd_params;
+
+typedef struct flacamd_encoder flacamd_encoder;
+typedef struct flacamd_decoder flacamd_decoder;
+
+/* Fill the analysis fields for compression level 0..8 (compression_levels_[],
+ * stream_encoder.c:127-148; FLAC__stream_encoder_set_compression_level :1455-1495). */
+void flacamd_params_preset(flacamd_params *p, unsigned level);
+/* Resolve defaults and validate like init_stream_internal_ (stream_encoder.c:667-766).
+ * Returns 0, FLACAMD_E_INVALID_ARGUMENT, or FLACAMD_E_UNSUPPORTED. */
+int flacamd_params_resolve(flacamd_params *p);
+/* One apodization window of length L into w[L] (window.c:49-223), computed on the host. */
+void flacamd_window(uint32_t type, float param, int32_t L, float *w);
+
+/* Create an encoder bound to HIP device `device` able to take up to max_frames frames per
+ * batch.  Allocates all device workspace once (replaces resize_buffers_, stream_encoder.c:2250). */
+int flacamd_encoder_create(flacamd_encoder **out, int device, const flacamd_params *params, uint32_t max_frames);
+void flacamd_encoder_destroy(flacamd_encoder *e);
+/* Resolved parameters (blocksize, precision filled in). */
+const flacamd_params *flacamd_encoder_params(const flacamd_encoder *e);
+/* Upper bound of the bytes one batch of `nframes` frames can produce. */
+size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nframes);
+
+/* Encode a run of consecutive blocks of ONE stream, PCM already in device memory.
+ *   d_pcm          nsamples wide samples, interleaved, layout pcm_format
+ *   nsamples       all blocks are full (blocksize samples) except that, when `final_block`
+ *                  is nonzero, the last one may be short: it is then coded as the
+ *                  reference's finish() codes it (stream_encoder.c:1322-1327: partition
+ *                  order 0, head of the full-length window).  Without final_block,
+ *                  nsamples must be a multiple of blocksize.
+ *   first_frame_number  number of the first frame of the batch (frame header, :2952)
+ *   prev_assignment     channel assignment of the frame before the batch, only read for
+ *                  loose mid/side streams whose batch does not start a decision period
+ *                  (stream_encoder.c:2958-2967); pass 0 otherwise
+ *   d_out / out_cap     device buffer receiving the frames back to back
+ *   d_frame_bytes  device array [nframes]: size of each frame
+ *   h_total_bytes  host: receives the total (this call synchronises the stream once at
+ *                  its end to read it and the status word); may be NULL
+ * Returns 0 or a negative error; on FLACAMD_E_FRAME_OVERFLOW no output is valid. */
+int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream);
+
+/* Same with host buffers: copies PCM in, frames and sizes out (PCIe inclusive). */
+int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	uint8_t *h_out, size_t out_cap, uint32_t *h_frame_bytes, uint64_t *h_total_bytes, uint32_t *h_last_assignment);
+
+/* White-box views of the last batch for parity tests (device -> host copies):
+ *   what = 0: float autoc[num_apod][max_lpc_order+1][nsignals]   (lpc.c:63-110 outputs)
+ *   what = 1: uint64 fixed_err[5][nsignals]                       (fixed.c:234-243 sums)
+ *   what = 2: uint32 winner header words [nsignals][4]            (see engine_types.h)
+ *   what = 3: uint32 estimated bits of the winning subframe [nsignals]
+ *   what = 4: uint8 wasted bits [nsignals]
+ * nsignals = frames x (4 for mid/side stereo, else channels). Returns bytes written or <0. */
+long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h_dst, size_t cap);
+
+/* Kernel time of the stages of the last batch in milliseconds, measured with HIP events on
+ * the stream the kernels ran on: ms[0..5] = prep, autocorrelation, model, search, pack, gather.
+ * Valid only when the batch was submitted with timing enabled. */
+void flacamd_encoder_set_timing(flacamd_encoder *e, int enabled);
+int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6]);
+
+/* MD5 of the unencoded PCM as FLAC__MD5Accumulate sees it (md5.c:273-420): one digest per
+ * independent stream of a batch, computed on the device, one lane per stream.
+ * d_pcm holds the streams back to back; h_offsets[nstreams+1] are wide-sample offsets. */
+int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
+	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests /* [nstreams][16] */, void *stream);
+
+/* ---- decoder ---------------------------------------------------------------------- */
+
+/* Decoder for streams of known channels / bits_per_sample / max blocksize (from STREAMINFO). */
+int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_t channels, uint32_t bits_per_sample,
+	uint32_t max_blocksize, uint32_t max_frames, size_t max_bytes);
+void flacamd_decoder_destroy(flacamd_decoder *d);
+
+/* Decode a byte range of frames held in device memory (no metadata): finds the frame
+ * boundaries (sync code + header CRC-8 + frame CRC-16, stream_decoder.c:1947-2145),
+ * decodes every frame in parallel and writes interleaved PCM (pcm_format) to d_pcm in
+ * stream order.  h_info[0]=frames, [1]=wide samples, [2]=first frame number,
+ * [3]=bytes consumed. */
+int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, size_t nbytes,
+	void *d_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4], void *stream);
+int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, size_t nbytes,
+	void *h_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4]);
+
+const char *flacamd_strerror(int code);
+/* Text of the last failing HIP call on this thread ("" if none). */
+const char *flacamd_last_error(void);
+/* Number of HIP devices visible, or 0. Does not initialise a context. */
+int flacamd_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
