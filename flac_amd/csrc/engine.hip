@@ -114,7 +114,7 @@ extern "C" void flacamd_window(uint32_t type, float param, int32_t L, float *w)
 		else { for(n = 0; n <= L/2-1; n++) w[n] = 2.0f * n / (float)N; for(; n <= N; n++) w[n] = 2.0f - 2.0f * (N-n) / (float)N; }
 		break;
 	case FLACAMD_WIN_BARTLETT_HANN:
-		for(n = 0; n < L; n++) w[n] = (float)(0.62f - 0.48f * fabs((float)n/(float)N+0.5f) + 0.38f * cos(2.0f * M_PI * ((float)n/(float)N+0.5f)));
+		for(n = 0; n < L; n++) w[n] = (float)(0.62f - 0.48f * fabs((double)((float)n/(float)N+0.5f))  /* C's fabs() takes and returns double (window.c:74) */ + 0.38f * cos(2.0f * M_PI * ((float)n/(float)N+0.5f)));
 		break;
 	case FLACAMD_WIN_BLACKMAN:
 		for(n = 0; n < L; n++) w[n] = (float)(0.42f - 0.5f * cos(2.0f * M_PI * n / N) + 0.08f * cos(4.0f * M_PI * n / N));

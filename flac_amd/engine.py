@@ -46,6 +46,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError("%s not built; run __graft_entry__.build()" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime; two runtimes in one process fight over the
+        # device, so when torch is installed it is imported first and libflacamd.so then binds
+        # to the runtime torch already loaded (torch provides the device buffers and streams).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
         L.flacamd_params_preset.argtypes = [C.POINTER(Params), C.c_uint]

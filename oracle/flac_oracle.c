@@ -821,6 +821,14 @@ long fo_encode_stream(const fo_params *pin, const int32_t *pcm, uint64_t nsample
 	uint32_t *frame_bytes, uint32_t *frame_samples, uint32_t max_frames,
 	fo_frame_info *infos, uint8_t md5[16])
 {
+	return fo_encode_stream_ex(pin, pcm, nsamples, 0, 1, out, cap, outlen, frame_bytes, frame_samples, max_frames, infos, md5);
+}
+
+long fo_encode_stream_ex(const fo_params *pin, const int32_t *pcm, uint64_t nsamples, uint32_t first_frame_number, int final_block,
+	uint8_t *out, size_t cap, size_t *outlen,
+	uint32_t *frame_bytes, uint32_t *frame_samples, uint32_t max_frames,
+	fo_frame_info *infos, uint8_t md5[16])
+{
 	fo_params p = *pin; coder_ctx c; ms_state ms; subframe_plan plans[4];
 	int32_t *sig[4], *chanbuf[FO_MAX_CHANNELS]; const int32_t *chan[FO_MAX_CHANNELS];
 	float *windows; unsigned N, ch, i; uint64_t pos = 0; long nframes = 0; size_t used = 0; long rc = 0;
@@ -844,7 +852,7 @@ long fo_encode_stream(const fo_params *pin, const int32_t *pcm, uint64_t nsample
 	for(ch = 0; ch < p.channels; ch++) { chanbuf[ch] = (int32_t*)malloc(sizeof(int32_t) * N); chan[ch] = chanbuf[ch]; }
 	/* stream_encoder.c:878-890 */
 	ms.loose_period = (unsigned)((double)p.sample_rate * 0.4 / (double)N + 0.5); if(ms.loose_period == 0) ms.loose_period = 1;
-	ms.loose_count = 0; ms.last_assignment = 0;
+	ms.loose_count = first_frame_number % ms.loose_period; ms.last_assignment = 0;
 
 	/* Blocking as FLAC__stream_encoder_process_interleaved + _finish (stream_encoder.c:2025-2105, :1322-1327):
 	 * a block is coded once blocksize+1 samples are known, so every full block except a
@@ -852,11 +860,11 @@ long fo_encode_stream(const fo_params *pin, const int32_t *pcm, uint64_t nsample
 	 * samples) is coded by finish() with fractional = (remaining != N). */
 	while(pos < nsamples) {
 		const uint64_t left = nsamples - pos; const unsigned n = left > N ? N : (unsigned)left;
-		const int fractional = (n != N);
+		const int fractional = (n != N) && final_block;
 		size_t fb;
 		if((uint32_t)nframes >= max_frames && frame_bytes) { rc = -3; break; }
 		for(i = 0; i < n; i++) for(ch = 0; ch < p.channels; ch++) chanbuf[ch][i] = pcm[(pos + i) * p.channels + ch];
-		fb = encode_frame(&c, chan, n, fractional, (uint32_t)nframes, &ms, plans, sig, out + used, cap - used, infos ? &infos[nframes] : 0);
+		fb = encode_frame(&c, chan, n, fractional, first_frame_number + (uint32_t)nframes, &ms, plans, sig, out + used, cap - used, infos ? &infos[nframes] : 0);
 		if(fb == 0) { rc = -2; break; }
 		if(frame_bytes) frame_bytes[nframes] = (uint32_t)fb;
 		if(frame_samples) frame_samples[nframes] = n;
@@ -872,6 +880,13 @@ long fo_encode_stream(const fo_params *pin, const int32_t *pcm, uint64_t nsample
 }
 
 /* ------------------------------------------------------------------ stream head */
+
+void fo_utf8(uint32_t v, uint8_t out[8], uint32_t *len)
+{
+	bitsink s; s.p = out; s.cap = 8; s.nbits = 0; s.overflow = 0;
+	put_utf8(&s, v);
+	*len = (uint32_t)(s.nbits >> 3);
+}
 
 void fo_write_stream_head(uint8_t out[42], uint32_t min_blocksize, uint32_t max_blocksize,
 	uint32_t min_framesize, uint32_t max_framesize, uint32_t sample_rate, uint32_t channels,

