@@ -240,6 +240,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		const size_t sub = ((size_t)p.blocksize * (maxbps + 1u) + 8u + 32u + 32u * (maxbps + 15u) + 64u + 7u) / 8u + 8u;
 		c.slot_bytes = (uint32_t)align_up(16u + p.channels * sub + 2u + 16u, 16u);
 	}
+	{ const char *dbg = getenv("FLACAMD_DEBUG"); c.debug = dbg ? (uint32_t)strtoul(dbg, 0, 0) : 0u; }
 	e->cand_group = c.max_cand < 24u ? c.max_cand : 24u;
 	if(e->cand_group == 0) e->cand_group = 1;
 	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
@@ -333,7 +334,7 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 	if(tm) hipEventRecord(e->ev[3], st);
 	fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
 	if(tm) hipEventRecord(e->ev[4], st);
-	fa_launch_pack(d_pcm, &c, &e->work, st);
+	if(!(c.debug & 3u)) fa_launch_pack(d_pcm, &c, &e->work, st);
 	if(tm) hipEventRecord(e->ev[5], st);
 	fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
 	if(tm) hipEventRecord(e->ev[6], st);

@@ -38,6 +38,7 @@ struct FaCfg {
 	uint32_t wide_fixed;      // 64-bit fixed-predictor error sums (stream_encoder.c:894)
 	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
 	uint32_t G;               // F * nsig
+	uint32_t debug;           // development ablation switches (FLACAMD_DEBUG), 0 in production
 };
 
 // Candidate header word written by the model kernel, read by the search kernel.

@@ -35,6 +35,16 @@ __device__ __forceinline__ uint32_t abs_u32(int32_t r) { return (uint32_t)(r < 0
 
 enum { MAC_I24 = 0, MAC_I32 = 1, MAC_WIDE = 2 };
 
+// d = a * b + c on the 24-bit multiplier (full rate); the low 32 bits of the sum are exact
+// for |a|, |b| < 2^23.  Written as asm so that the chain stays one instruction per tap
+// (the compiler otherwise splits it into two multiplies and a three-operand add).
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)
+{
+	int32_t d;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+
 // |residual| sums of one 16-sample chunk for an order-P predictor.  `head` collects the
 // first P samples of the chunk (they are warm-up samples, not residuals, when the chunk
 // is the first of the frame), `tail` the rest.
@@ -54,7 +64,7 @@ __device__ __forceinline__ void lpc_chunk(const int32_t (&xw)[HIST + CH], const 
 		else if(MODE == MAC_I24) {
 			int32_t acc = 0;
 #pragma unroll
-			for(int j = 0; j < P; j++) acc = __mul24(q[j], xw[HIST + s - 1 - j]) + acc; // low 32 bits of the sum: same wrap as lpc.c:296
+			for(int j = 0; j < P; j++) acc = mad24(q[j], xw[HIST + s - 1 - j], acc); // low 32 bits of the sum: same wrap as lpc.c:296
 			pred = acc >> shift;
 		}
 		else {
@@ -141,13 +151,19 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	// LDS carve-up
 	const uint32_t xs_words = ((c.N + 32u) * 17u) / 16u + 17u;
 	int32_t *xs = (int32_t*)lds_raw;
-	unsigned long long *psum = (unsigned long long*)(lds_raw + (((size_t)xs_words * 4u + 15u) & ~(size_t)15u)); // [cg][FA_MAX_PARTS rows trimmed to parts_cap]
+	// |residual| sums of every partition at every order: row ci holds the finest order first
+	// (parts0 entries), then each coarser order, 2*parts0 - 1 entries in all
+	unsigned long long *psum = (unsigned long long*)(lds_raw + (((size_t)xs_words * 4u + 15u) & ~(size_t)15u)); // [cg][2 * parts_cap]
 	const uint32_t parts_cap = 1u << (c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER);
-	uint32_t *lbits = (uint32_t*)(psum + (size_t)cg * parts_cap);                 // [cg][16]
+	const uint32_t prow = 2u * parts_cap;
+	uint32_t *lbits = (uint32_t*)(psum + (size_t)cg * prow);                      // [cg][16]
 	unsigned long long *ckey = (unsigned long long*)(lbits + (size_t)cg * 16u);    // [cg]
 	uint32_t *cpo = (uint32_t*)(ckey + cg);                                        // [cg]
 	uint8_t *kbuf = (uint8_t*)(cpo + cg);                                          // [cg][2*parts_cap]
 	uint8_t *best_k = kbuf + (size_t)cg * 2u * parts_cap;                          // [parts_cap]
+	uint32_t *chdr = (uint32_t*)(lds_raw + (((size_t)(best_k + parts_cap - lds_raw) + 3u) & ~(size_t)3u));                              // [cg] candidate headers of the current group
+	int32_t *cq = (int32_t*)(chdr + cg);                                           // [cg][HIST] coefficients (orders <= HIST)
+	uint32_t *cinfo = (uint32_t*)(cq + (size_t)cg * HIST);                         // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
 
 	// ---- stage the signal: xs[-32..-1] = 0, xs[0..n) = signal >> wasted, zero up to the next chunk boundary
 	if(tid == 0) { sh.have_best = 0; sh.best_est = 0; sh.best_cand = 0xffffffffu; sh.best_po = 0; sh.rice2 = 0; }
@@ -162,12 +178,27 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 
 	for(uint32_t cb = 0; cb < ncand; cb += cg) {
 		const uint32_t gn = (ncand - cb) < cg ? (ncand - cb) : cg;
-		for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * parts_cap + (t % parts0)] = 0;
+		for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * prow + (t % parts0)] = 0;
 		for(uint32_t t = tid; t < gn * 16u; t += 256) lbits[t] = 0;
+		// candidate headers and coefficients of this group: one parallel fetch into LDS
+		for(uint32_t t = tid; t < gn; t += 256) chdr[t] = w.cand_hdr[(size_t)(cb + t) * c.G + g];
+		for(uint32_t t = tid; t < gn * HIST; t += 256) {
+			const uint32_t ci = t / HIST, j = t - ci * HIST;
+			cq[t] = (j < qrows) ? w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] : 0;
+		}
 		__syncthreads();
+		if(tid < gn) {
+			const uint32_t order = FA_CAND_ORDER(chdr[tid]);
+			const uint32_t maxpo_c = limit_po(maxpo_f, n, order);
+			const uint32_t minpo_c = minpo_f < maxpo_c ? minpo_f : maxpo_c;
+			// the reference's accumulator at the candidate's own finest order wraps at 32 bits when
+			// ilog2(partition length) + bps < 32 (stream_encoder.c:3808)
+			const uint32_t narrow_c = (fa_ilog2(n >> maxpo_c) + bps < 32u) ? 1u : 0u;
+			cinfo[tid] = order | (maxpo_c << 8) | (minpo_c << 12) | (narrow_c << 16);
+		}
 
 		// ---- |residual| sums per finest partition
-		if(fast) {
+		if(fast && !(c.debug & 1u)) {
 			const uint32_t cpp = dps0 / CH; // chunks per finest partition
 			for(uint32_t chunk = tid; chunk * CH < n; chunk += 256) {
 				int32_t xw[HIST + CH];
@@ -175,7 +206,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 				for(int j = 0; j < HIST + CH; j++) xw[j] = xs[xs_idx((int32_t)(chunk * CH) - HIST + j)];
 				const uint32_t part = chunk / cpp;
 				for(uint32_t ci = 0; ci < gn; ci++) {
-					const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr);
 					SUM head = 0, tail = 0;
 					if(FA_CAND_KIND(hdr) == 0) {
@@ -190,7 +221,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 					else if(order <= HIST) {
 						int32_t q[HIST];
 #pragma unroll
-						for(int j = 0; j < HIST; j++) q[j] = ((uint32_t)j < order) ? w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] : 0;
+						for(int j = 0; j < HIST; j++) q[j] = cq[ci * HIST + j];
 						const uint32_t shift = FA_CAND_SHIFT(hdr);
 						if(FA_CAND_WIDE(hdr)) lpc_chunk_dispatch<MAC_WIDE, SUM>(order, xw, q, shift, head, tail);
 						else if(bps <= 24) lpc_chunk_dispatch<MAC_I24, SUM>(order, xw, q, shift, head, tail);
@@ -198,14 +229,14 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 					}
 					else continue; // high orders: generic pass below
 					const SUM v = tail + (chunk == 0 ? (SUM)0 : head);
-					if(sizeof(SUM) == 4) atomicAdd((uint32_t*)&psum[(size_t)ci * parts_cap + part], (uint32_t)v);
-					else atomicAdd(&psum[(size_t)ci * parts_cap + part], (unsigned long long)v);
+					if(sizeof(SUM) == 4) atomicAdd((uint32_t*)&psum[(size_t)ci * prow + part], (uint32_t)v);
+					else atomicAdd(&psum[(size_t)ci * prow + part], (unsigned long long)v);
 				}
 			}
 		}
 		// generic per-sample pass: any frame length / partition length, and orders above HIST
 		for(uint32_t ci = 0; ci < gn; ci++) {
-			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
+			const uint32_t hdr = chdr[ci];
 			const uint32_t order = FA_CAND_ORDER(hdr), kind = FA_CAND_KIND(hdr);
 			if(fast && (kind == 0 || order <= HIST)) continue;
 			const uint32_t shift = FA_CAND_SHIFT(hdr), wide = FA_CAND_WIDE(hdr);
@@ -230,40 +261,62 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 					}
 					r = (int32_t)((uint32_t)xs[xs_idx((int32_t)i)] - (uint32_t)pred);
 				}
-				atomicAdd(&psum[(size_t)ci * parts_cap + i / dps0], (unsigned long long)abs_u32(r));
+				atomicAdd(&psum[(size_t)ci * prow + i / dps0], (unsigned long long)abs_u32(r));
 			}
 		}
 		__syncthreads();
 
-		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition)
-		const uint32_t per = 2u * parts0;
-		for(uint32_t t = tid; t < gn * per; t += 256) {
-			const uint32_t ci = t / per, idx = t - ci * per;
-			if(idx >= per - 1u) continue;
-			// idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
-			uint32_t lvl = 0, off = 0, cnt = parts0;
-			while(idx >= off + cnt) { off += cnt; cnt >>= 1; lvl++; }
-			const uint32_t po = maxpo_f - lvl, p = idx - off;
-			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
-			const uint32_t order = FA_CAND_ORDER(hdr);
-			const uint32_t maxpo_c = limit_po(maxpo_f, n, order);
-			const uint32_t minpo_c = minpo_f < maxpo_c ? minpo_f : maxpo_c;
-			if(po > maxpo_c || po < minpo_c) continue;
-			// sum of the finest-level sums below this partition; the reference's accumulator at the
-			// candidate's own finest order wraps at 32 bits when ilog2(partition length) + bps < 32
-			const bool narrow_c = fa_ilog2(n >> maxpo_c) + bps < 32u;
-			const uint32_t group = 1u << (maxpo_f - maxpo_c), mids = 1u << (maxpo_c - po);
-			unsigned long long sum = 0;
-			for(uint32_t a = 0; a < mids; a++) {
-				unsigned long long sub = 0;
-				for(uint32_t b = 0; b < group; b++) sub += psum[(size_t)ci * parts_cap + (p * mids + a) * group + b];
-				if(narrow_c) sub &= 0xffffffffull;
-				sum += sub;
+		// ---- sums of the coarser partition orders: pairwise merges, three orders per barrier.
+		// A value read at the candidate's own finest order is first wrapped to 32 bits when the
+		// reference's accumulator there is 32 bits wide.
+		for(uint32_t l0 = 0; l0 < maxpo_f; l0 += 3) {
+			const uint32_t lto = (l0 + 3u < maxpo_f) ? l0 + 3u : maxpo_f, span = lto - l0;
+			const uint32_t cnt_to = parts0 >> lto, fan = 1u << span;
+			for(uint32_t t = tid; t < gn * cnt_to; t += 256) {
+				const uint32_t ci = t / cnt_to, pg = t - ci * cnt_to;
+				const uint32_t info = cinfo[ci];
+				const uint32_t lvl_c = maxpo_f - ((info >> 8) & 15u);
+				const bool narrow_c = (info >> 16) & 1u;
+				unsigned long long *row = psum + (size_t)ci * prow;
+				unsigned long long v[8];
+				const uint32_t off0 = 2u * parts0 - ((2u * parts0) >> l0);
+#pragma unroll
+				for(uint32_t i = 0; i < 8; i++) if(i < fan) { v[i] = row[off0 + pg * fan + i]; if(narrow_c && l0 == lvl_c) v[i] &= 0xffffffffull; }
+				uint32_t width = fan;
+#pragma unroll
+				for(uint32_t d = 1; d <= 3; d++) if(d <= span) {
+					width >>= 1;
+					const uint32_t lv = l0 + d, off = 2u * parts0 - ((2u * parts0) >> lv);
+#pragma unroll
+					for(uint32_t i = 0; i < 4; i++) if(i < width) {
+						unsigned long long m = v[2*i] + v[2*i+1];
+						row[off + pg * width + i] = m;
+						if(narrow_c && lv == lvl_c) m &= 0xffffffffull;
+						v[i] = m;
+					}
+				}
 			}
+			__syncthreads();
+		}
+
+		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition)
+		const uint32_t per = 2u * parts0, per_log = maxpo_f + 1u;
+		for(uint32_t t = tid; t < ((c.debug & 2u) ? 0u : gn * per); t += 256) {
+			const uint32_t ci = t >> per_log, idx = t & (per - 1u);
+			if(idx == per - 1u) continue;
+			// idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
+			const uint32_t lvl = per_log - (32u - (uint32_t)__clz((int)(per - idx - 1u)));
+			const uint32_t off = per - (per >> lvl);
+			const uint32_t po = maxpo_f - lvl, p = idx - off;
+			const uint32_t info = cinfo[ci];
+			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
+			if(po > maxpo_c || po < minpo_c) continue;
+			unsigned long long sum = psum[(size_t)ci * prow + idx];
+			if(((info >> 16) & 1u) && po == maxpo_c) sum &= 0xffffffffull;
 			const uint32_t nsamp = (n >> po) - (p == 0 ? order : 0u);
 			uint32_t k;
-			if(po == 0) k = FA_CAND_K(hdr);   // stream_encoder.c:3982-4029
-			else {                             // :4052 smallest k with nsamp << k >= sum
+			if(po == 0) k = FA_CAND_K(chdr[ci]);   // stream_encoder.c:3982-4029
+			else {                                  // :4052 smallest k with nsamp << k >= sum
 				k = 0;
 				if(sum > (unsigned long long)nsamp) {
 					const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)sum), bl_n = 32u - (uint32_t)__clz((int)nsamp);
@@ -282,10 +335,8 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 		// ---- best partition order of each candidate (searched max -> min, strict '<'), subframe estimate
 		if(tid < gn) {
 			const uint32_t ci = tid;
-			const uint32_t hdr = w.cand_hdr[(size_t)(cb + ci) * c.G + g];
-			const uint32_t order = FA_CAND_ORDER(hdr);
-			const uint32_t maxpo_c = limit_po(maxpo_f, n, order);
-			const uint32_t minpo_c = minpo_f < maxpo_c ? minpo_f : maxpo_c;
+			const uint32_t hdr = chdr[ci], info = cinfo[ci];
+			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
 			uint32_t best = 0, bestpo = 0; bool have = false;
 			for(int po = (int)maxpo_c; po >= (int)minpo_c; po--) {
 				const uint32_t b = 6u + lbits[ci * 16u + (maxpo_f - (uint32_t)po)];
@@ -352,12 +403,16 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 	const size_t xs_words = ((size_t)(c->N + 32u) * 17u) / 16u + 17u;
 	const size_t parts_cap = (size_t)1 << (c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER);
 	size_t b = (xs_words * 4u + 15u) & ~(size_t)15u;
-	b += (size_t)cg * parts_cap * 8u;  // psum
+	b += (size_t)cg * 2u * parts_cap * 8u;  // psum, all partition orders
 	b += (size_t)cg * 16u * 4u;        // lbits
 	b += (size_t)cg * 8u;              // ckey
 	b += (size_t)cg * 4u;              // cpo
 	b += (size_t)cg * 2u * parts_cap;  // kbuf
 	b += parts_cap;                    // best_k
+	b = (b + 3u) & ~(size_t)3u;
+	b += (size_t)cg * 4u;              // chdr
+	b += (size_t)cg * HIST * 4u;       // cq
+	b += (size_t)cg * 4u;              // cinfo
 	return (b + 15u) & ~(size_t)15u;
 }
 

@@ -1,0 +1,90 @@
+// Micro-benchmark: issue rate of the integer VALU instructions the search kernel could use.
+// Each kernel runs 8 independent chains of one instruction, 4096 iterations x 8, on
+// 256 CUs x 8 waves/SIMD.  Prints wave-instructions per cycle-equivalent (ns per instr per SIMD).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#define ITERS 2048
+#define DEF_KERNEL(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(int *out, int a, int b) { \
+	int x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+	int va = a + threadIdx.x, vb = b ^ threadIdx.x; \
+	for(int i = 0; i < ITERS; i++) { \
+		asm volatile(ASM(%0) "\n" ASM(%1) "\n" ASM(%2) "\n" ASM(%3) "\n" ASM(%4) "\n" ASM(%5) "\n" ASM(%6) "\n" ASM(%7) \
+			: "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(va), "v"(vb)); \
+	} \
+	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7; \
+}
+#define A_MAD24(x) "v_mad_i32_i24 " #x ", %8, %9, " #x
+#define A_MUL24(x) "v_mul_i32_i24 " #x ", %8, " #x
+#define A_ADD(x) "v_add_u32 " #x ", %8, " #x
+#define A_ADD3(x) "v_add3_u32 " #x ", %8, %9, " #x
+#define A_MULLO(x) "v_mul_lo_u32 " #x ", %8, " #x
+#define A_DOT2(x) "v_dot2_i32_i16 " #x ", %8, %9, " #x
+#define A_DOT4(x) "v_dot4_i32_i8 " #x ", %8, %9, " #x
+#define A_SAD(x) "v_sad_u32 " #x ", %8, %9, " #x
+#define A_MAXI(x) "v_max_i32 " #x ", %8, " #x
+#define A_FMA(x) "v_fma_f32 " #x ", %8, %9, " #x
+#define A_MADI16(x) "v_mad_i32_i16 " #x ", %8, %9, " #x
+#define A_PKMAD(x) "v_pk_mad_i16 " #x ", %8, %9, " #x
+#define A_ASHR(x) "v_ashrrev_i32 " #x ", 3, " #x
+#define A_MADU24(x) "v_mad_u32_u24 " #x ", %8, %9, " #x
+#define A_LSHLADD(x) "v_lshl_add_u32 " #x ", %8, 2, " #x
+#define A_MULF(x) "v_mul_f32 " #x ", %8, " #x
+#define A_PKFMA(x) "v_pk_fma_f32 " #x ", %8, %9, " #x
+DEF_KERNEL(k_mad24, A_MAD24)
+DEF_KERNEL(k_mul24, A_MUL24)
+DEF_KERNEL(k_add, A_ADD)
+DEF_KERNEL(k_add3, A_ADD3)
+DEF_KERNEL(k_mullo, A_MULLO)
+DEF_KERNEL(k_dot2, A_DOT2)
+DEF_KERNEL(k_dot4, A_DOT4)
+DEF_KERNEL(k_sad, A_SAD)
+DEF_KERNEL(k_maxi, A_MAXI)
+DEF_KERNEL(k_fma, A_FMA)
+DEF_KERNEL(k_madi16, A_MADI16)
+DEF_KERNEL(k_pkmad, A_PKMAD)
+DEF_KERNEL(k_ashr, A_ASHR)
+DEF_KERNEL(k_madu24, A_MADU24)
+DEF_KERNEL(k_lshladd, A_LSHLADD)
+DEF_KERNEL(k_mulf, A_MULF)
+
+__global__ void __launch_bounds__(256) k_mad64(long long *out, int a, int b) {
+	long long x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+	int va = a + threadIdx.x, vb = b ^ threadIdx.x;
+	for(int i = 0; i < ITERS; i++) {
+		asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\nv_mad_i64_i32 %1, vcc, %4, %5, %1\nv_mad_i64_i32 %2, vcc, %4, %5, %2\nv_mad_i64_i32 %3, vcc, %4, %5, %3\n"
+			"v_mad_i64_i32 %0, vcc, %4, %5, %0\nv_mad_i64_i32 %1, vcc, %4, %5, %1\nv_mad_i64_i32 %2, vcc, %4, %5, %2\nv_mad_i64_i32 %3, vcc, %4, %5, %3"
+			: "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(va), "v"(vb) : "vcc");
+	}
+	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
+}
+
+template<typename K, typename T>
+static void run(const char *name, K kern, T *buf)
+{
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const int blocks = 256 * 8; // 8 blocks of 4 waves per CU -> 8 waves per SIMD
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, buf, 3, 5);
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, buf, 3, 5);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	// wave-instructions per SIMD: 8 waves x ITERS x 8
+	const double per_simd = 8.0 * ITERS * 8.0;
+	printf("%-12s %8.3f ms  %6.2f ns per wave-instr per SIMD  (= %5.2f cycles at 2.4 GHz)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+}
+
+int main()
+{
+	int *buf; hipMalloc(&buf, 256 * 8 * 256 * 8);
+	run("mad_i32_i24", k_mad24, buf); run("mul_i32_i24", k_mul24, buf); run("mad_u32_u24", k_madu24, buf); run("add_u32", k_add, buf); run("add3_u32", k_add3, buf);
+	run("mul_lo_u32", k_mullo, buf); run("dot2_i32_i16", k_dot2, buf); run("dot4_i32_i8", k_dot4, buf); run("sad_u32", k_sad, buf);
+	run("max_i32", k_maxi, buf); run("fma_f32", k_fma, buf); run("mul_f32", k_mulf, buf); run("mad_i32_i16", k_madi16, buf); run("pk_mad_i16", k_pkmad, buf);
+	run("ashrrev_i32", k_ashr, buf); run("lshl_add_u32", k_lshladd, buf);
+	run("mad_i64_i32", k_mad64, (long long*)buf);
+	return 0;
+}
