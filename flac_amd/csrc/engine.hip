@@ -255,7 +255,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_chdr = take((size_t)c.max_cand * G * 4), o_cq = take((size_t)c.max_cand * qrows * G * 4),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4);
+		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes));
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
 	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
@@ -265,6 +265,27 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_chdr); w.cand_q = (int32_t*)(b + o_cq);
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg);
 	w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
+
+	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
+	{
+		uint32_t words = 0;
+		fa_pack_lds_bytes(&c, &words);
+		uint16_t *tab = (uint16_t*)malloc(sizeof(uint16_t) * (1024u + words + 1u));
+		if(!tab) { hipFree(e->arena); free(e); return FLACAMD_E_OUT_OF_MEMORY; }
+		for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }
+		// tab[256*z + b]: the byte followed by z zero bytes (feeding a zero byte multiplies by x^8)
+		for(unsigned z = 1; z < 4; z++) for(unsigned bb = 0; bb < 256; bb++) { const unsigned v = tab[256 * (z - 1) + bb]; tab[256 * z + bb] = (uint16_t)(((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]); }
+		// x^(32 w): feed 4 w zero bytes after a register holding 1
+		unsigned v = 1;
+		for(unsigned wv = 0; wv <= words; wv++) {
+			tab[1024 + wv] = (uint16_t)v;
+			for(unsigned z = 0; z < 4; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu];
+		}
+		he = hipMemcpy(b + o_crc, tab, sizeof(uint16_t) * (1024u + words + 1u), hipMemcpyHostToDevice);
+		free(tab);
+		if(he != hipSuccess) { rc = hip_fail(he, "hipMemcpy(crc tables)"); hipFree(e->arena); free(e); return rc; }
+		w.crc16_table4 = (const uint16_t*)(b + o_crc); w.crc16_xpw = (const uint16_t*)(b + o_crc) + 1024;
+	}
 
 	// window tables, computed on the host exactly once per stream (resize_buffers_, stream_encoder.c:2318-2373)
 	{

@@ -98,6 +98,8 @@ struct FaWork {
 	uint32_t *status;      // [1] nonzero = some frame overflowed its slot
 	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
 	const float *window;   // [num_apod][N]
+	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
+	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial
 };
 
 #ifdef __HIPCC__

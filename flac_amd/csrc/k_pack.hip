@@ -17,8 +17,7 @@
 // CRC-16 is computed in parallel over the finished bytes (per-thread segment CRC, then a
 // GF(2) multiply by x^(8*bytes_after) and an XOR reduction).
 #include "engine_types.h"
-
-__device__ __forceinline__ uint32_t pk_xs_idx(int32_t i) { return (uint32_t)(i + 32); }
+#include "residual.h"
 
 // ---- CRC helpers (polynomials of crc.c:33-121: CRC-8 0x07, CRC-16 0x8005, init 0, MSB first)
 __device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte)
@@ -60,23 +59,13 @@ struct PackShared {
 	uint32_t carry_bits;   // valid bits in bitbuf[0] carried from what was written before
 	uint32_t words_out;    // 32-bit words already flushed to the slot
 	uint32_t overflow;
-	uint32_t crc;
+	uint32_t crc;          // CRC-16 of everything flushed so far
+	uint32_t crc_chunk;    // CRC-16 of the words being flushed
+	uint32_t hdr_bytes;
 	int32_t  q[FLACAMD_MAX_LPC_ORDER];
 	uint8_t  k[FA_MAX_PARTS];
+	uint16_t crc4[4][256]; // CRC-16 of one byte followed by 0..3 zero bytes
 };
-
-// OR `nbits` (1..32) low bits of v into the MSB-first bit buffer at bit position pos
-__device__ __forceinline__ void put_bits(uint32_t *buf, uint32_t pos, uint32_t v, uint32_t nbits)
-{
-	const uint32_t wi = pos >> 5, off = pos & 31u;
-	if(nbits < 32u) v &= (1u << nbits) - 1u;
-	if(off + nbits <= 32u) atomicOr(&buf[wi], v << (32u - off - nbits));
-	else {
-		const uint32_t spill = off + nbits - 32u;
-		atomicOr(&buf[wi], v >> spill);
-		atomicOr(&buf[wi + 1], v << (32u - spill));
-	}
-}
 
 // exclusive scan of one value per thread over the 256-thread workgroup; returns the
 // exclusive prefix and the total through `total`
@@ -96,40 +85,73 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, PackShared &sh, uin
 	return pre + inc - v;
 }
 
-// residual of sample i (i >= order) of the staged signal
-__device__ __forceinline__ int32_t residual_at(const int32_t *xs, uint32_t i, uint32_t type, uint32_t order, uint32_t shift, uint32_t wide, const int32_t *q)
+// Per-thread bit writer: a run of tokens at increasing bit positions.  Words that lie
+// strictly inside the thread's run are stored whole; the first and the last word may be
+// shared with the neighbouring threads and are OR-ed atomically.  The buffer is zero
+// beforehand, so zero runs are skipped without touching memory.
+struct BitRun {
+	uint32_t *buf; uint32_t pos, wi, first_wi, cur;
+	__device__ __forceinline__ void begin(uint32_t *b, uint32_t p) { buf = b; pos = p; wi = first_wi = p >> 5; cur = 0; }
+	__device__ __forceinline__ void store_word() { if(cur) { if(wi == first_wi) atomicOr(&buf[wi], cur); else buf[wi] = cur; } }
+	__device__ __forceinline__ void zeros(uint32_t nz)
+	{
+		pos += nz;
+		const uint32_t nw = pos >> 5;
+		if(nw != wi) { store_word(); wi = nw; cur = 0; }
+	}
+	// nbits in 1..32, v already masked to nbits
+	__device__ __forceinline__ void put(uint32_t v, uint32_t nbits)
+	{
+		const uint32_t off = pos & 31u;
+		pos += nbits;
+		if(off + nbits < 32u) cur |= v << (32u - off - nbits);
+		else {
+			const uint32_t spill = off + nbits - 32u;
+			cur |= spill ? (v >> spill) : v;
+			store_word();
+			wi++;
+			cur = spill ? (v << (32u - spill)) : 0u;
+		}
+	}
+	__device__ __forceinline__ void end() { if(cur) atomicOr(&buf[wi], cur); }
+};
+
+// CRC-16 of n 32-bit big-endian words starting at p, register starting at 0 (slice by four)
+__device__ __forceinline__ uint32_t crc16_words(const uint32_t *p, uint32_t n, const PackShared &sh)
 {
-	if(type == FA_SUB_FIXED) {
-		const uint32_t a = (uint32_t)xs[pk_xs_idx((int32_t)i)], b = (uint32_t)xs[pk_xs_idx((int32_t)i - 1)], c = (uint32_t)xs[pk_xs_idx((int32_t)i - 2)],
-		               d = (uint32_t)xs[pk_xs_idx((int32_t)i - 3)], e = (uint32_t)xs[pk_xs_idx((int32_t)i - 4)];
-		return (int32_t)(order == 0 ? a : order == 1 ? a - b : order == 2 ? a - 2u*b + c : order == 3 ? a - 3u*b + 3u*c - d : a - 4u*b + 6u*c - 4u*d + e);
+	uint32_t crc = 0;
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t v = p[i] ^ (crc << 16);
+		crc = (uint32_t)sh.crc4[3][v >> 24] ^ (uint32_t)sh.crc4[2][(v >> 16) & 255u] ^ (uint32_t)sh.crc4[1][(v >> 8) & 255u] ^ (uint32_t)sh.crc4[0][v & 255u];
 	}
-	int32_t pred;
-	if(wide) {
-		long long acc = 0;
-		for(uint32_t j = 0; j < order; j++) acc += (long long)q[j] * (long long)xs[pk_xs_idx((int32_t)(i - 1u - j))];
-		pred = (int32_t)(acc >> shift);
-	}
-	else {
-		uint32_t acc = 0;
-		for(uint32_t j = 0; j < order; j++) acc += (uint32_t)q[j] * (uint32_t)xs[pk_xs_idx((int32_t)(i - 1u - j))];
-		pred = (int32_t)acc >> shift;
-	}
-	return (int32_t)((uint32_t)xs[pk_xs_idx((int32_t)i)] - (uint32_t)pred);
+	return crc;
 }
 
-// Flush the completed words of the bit buffer (bits [0, total_bits)) to the slot and keep
-// the partial word as the new carry.  All threads call it.
-__device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bits, uint32_t *slot_words, PackShared &sh)
+// Flush the completed words of the bit buffer (bits [0, total_bits)) to the slot, fold them
+// into the running CRC-16, and keep the partial word as the new carry.  All threads call it.
+__device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bits, uint32_t *slot_words, PackShared &sh, const FaWork &w, uint32_t segw)
 {
-	const uint32_t full = total_bits >> 5, wo = sh.words_out;
+	const uint32_t full = total_bits >> 5, wo = sh.words_out, tid = threadIdx.x;
 	__syncthreads();
-	for(uint32_t i = threadIdx.x; i < full; i += 256) slot_words[wo + i] = __builtin_bswap32(bitbuf[i]);
+	for(uint32_t i = tid; i < full; i += 256) slot_words[wo + i] = __builtin_bswap32(bitbuf[i]);
+	// CRC of the chunk: thread j takes the segw words that end segw*j words before the end
+	{
+		const uint32_t e1 = (segw * tid < full) ? full - segw * tid : 0u, b0 = (e1 > segw) ? e1 - segw : 0u;
+		uint32_t crc = 0;
+		if(e1 > 0) crc = gf16_mul(crc16_words(bitbuf + b0, e1 - b0, sh), w.crc16_xpw[segw * tid]);
+#pragma unroll
+		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
+		if((tid & 63u) == 0 && crc) atomicXor(&sh.crc_chunk, crc);
+	}
 	const uint32_t partial = bitbuf[full];
 	__syncthreads();
-	for(uint32_t i = threadIdx.x; i <= full + 1u; i += 256) bitbuf[i] = 0;
+	for(uint32_t i = tid; i <= full + 1u; i += 256) bitbuf[i] = 0;
 	__syncthreads();
-	if(threadIdx.x == 0) { bitbuf[0] = partial; sh.carry_bits = total_bits & 31u; sh.words_out = wo + full; }
+	if(tid == 0) {
+		bitbuf[0] = partial; sh.carry_bits = total_bits & 31u; sh.words_out = wo + full;
+		sh.crc = gf16_mul(sh.crc, w.crc16_xpw[full]) ^ sh.crc_chunk;
+		sh.crc_chunk = 0;
+	}
 	__syncthreads();
 }
 
@@ -137,8 +159,8 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackShared sh;
-	int32_t *xs = (int32_t*)lds_raw;                       // [N + 32]
-	uint32_t *bitbuf = (uint32_t*)(xs + c.N + 32u);        // [bitbuf_words]
+	int32_t *xs = (int32_t*)lds_raw;                            // padded signal, xs_words_for(N) words
+	uint32_t *bitbuf = (uint32_t*)(xs + xs_words_for(c.N));     // [bitbuf_words]
 
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
 	const uint32_t n = fa_frame_len(c, f);
@@ -146,9 +168,11 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 	uint32_t *slot_words = (uint32_t*)(w.slots + (size_t)f * c.slot_bytes);
 	uint8_t *slot = w.slots + (size_t)f * c.slot_bytes;
 	const uint32_t cap_bits = (bitbuf_words - 2u) * 32u;
+	const uint32_t segw = (bitbuf_words + 255u) / 256u;
 
 	for(uint32_t i = tid; i < bitbuf_words; i += 256) bitbuf[i] = 0;
-	if(tid < 32) xs[tid] = 0;
+	if(tid < 32) xs[xs_idx((int32_t)tid - 32)] = 0;
+	for(uint32_t i = tid; i < 1024; i += 256) sh.crc4[i >> 8][i & 255u] = w.crc16_table4[i];
 	__syncthreads();
 
 	// ---- channel assignment (stream_encoder.c:3052-3087; loose rule :2958-2967, :3059-3061)
@@ -170,11 +194,10 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 			else a = c.prev_assignment;
 			if(cnt != 0) a = (a == 0) ? 0u : 3u; // followers only choose between independent and mid/side
 		}
-		sh.assignment = a; sh.carry_bits = 0; sh.words_out = 0; sh.overflow = 0; sh.crc = 0;
+		sh.assignment = a; sh.carry_bits = 0; sh.words_out = 0; sh.overflow = 0; sh.crc = 0; sh.crc_chunk = 0;
 		w.assignment[f] = a;
 
-		// ---- frame header (stream_encoder_framing.c:219-364), bytes built serially by one lane
-		uint8_t hb[16]; uint32_t nb = 0;
+		// ---- frame header (stream_encoder_framing.c:219-364), built by one lane
 		uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
 		switch(n) {
 		case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break; case 2304: bs_code = 4; break; case 4608: bs_code = 5; break;
@@ -195,39 +218,32 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		uint32_t bps_code;
 		switch(c.bps) { case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break; case 20: bps_code = 5; break; case 24: bps_code = 6; break; default: bps_code = 0; break; }
 		const uint32_t ch_code = (a == 0) ? c.channels - 1u : 7u + a;
-		hb[nb++] = 0xff; hb[nb++] = 0xf8;
-		hb[nb++] = (uint8_t)((bs_code << 4) | sr_code);
-		hb[nb++] = (uint8_t)((ch_code << 4) | (bps_code << 1));
-		{ // bitwriter.c:784-832
+		uint32_t nb = 0, crc = 0;
+		auto hb = [&](uint32_t byte) { byte &= 0xffu; crc = crc8_byte(crc, byte); bitbuf[nb >> 2] |= byte << (24u - 8u * (nb & 3u)); nb++; };
+		hb(0xff); hb(0xf8); hb((bs_code << 4) | sr_code); hb((ch_code << 4) | (bps_code << 1));
+		{ // frame number, bitwriter.c:784-832
 			const uint32_t v = c.first_frame + f;
-			if(v < 0x80u) hb[nb++] = (uint8_t)v;
-			else if(v < 0x800u) { hb[nb++] = (uint8_t)(0xC0u | (v >> 6)); hb[nb++] = (uint8_t)(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x10000u) { hb[nb++] = (uint8_t)(0xE0u | (v >> 12)); hb[nb++] = (uint8_t)(0x80u | ((v >> 6) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x200000u) { hb[nb++] = (uint8_t)(0xF0u | (v >> 18)); hb[nb++] = (uint8_t)(0x80u | ((v >> 12) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 6) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x4000000u) { hb[nb++] = (uint8_t)(0xF8u | (v >> 24)); hb[nb++] = (uint8_t)(0x80u | ((v >> 18) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 12) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 6) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | (v & 0x3Fu)); }
-			else { hb[nb++] = (uint8_t)(0xFCu | (v >> 30)); hb[nb++] = (uint8_t)(0x80u | ((v >> 24) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 18) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 12) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | ((v >> 6) & 0x3Fu)); hb[nb++] = (uint8_t)(0x80u | (v & 0x3Fu)); }
+			if(v < 0x80u) hb(v);
+			else if(v < 0x800u) { hb(0xC0u | (v >> 6)); hb(0x80u | (v & 0x3Fu)); }
+			else if(v < 0x10000u) { hb(0xE0u | (v >> 12)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+			else if(v < 0x200000u) { hb(0xF0u | (v >> 18)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+			else if(v < 0x4000000u) { hb(0xF8u | (v >> 24)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+			else { hb(0xFCu | (v >> 30)); hb(0x80u | ((v >> 24) & 0x3Fu)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
 		}
-		if(bs_hint == 6) hb[nb++] = (uint8_t)(n - 1u);
-		else if(bs_hint == 7) { hb[nb++] = (uint8_t)((n - 1u) >> 8); hb[nb++] = (uint8_t)(n - 1u); }
-		if(sr_hint == 12) hb[nb++] = (uint8_t)(c.rate / 1000u);
-		else if(sr_hint == 13) { hb[nb++] = (uint8_t)(c.rate >> 8); hb[nb++] = (uint8_t)c.rate; }
-		else if(sr_hint == 14) { hb[nb++] = (uint8_t)((c.rate / 10u) >> 8); hb[nb++] = (uint8_t)(c.rate / 10u); }
-		uint32_t crc = 0;
-		for(uint32_t i = 0; i < nb; i++) crc = crc8_byte(crc, hb[i]);
-		hb[nb++] = (uint8_t)crc;
-		sh.wave_tot[0] = nb; // header length handed to the flush below
-		for(uint32_t i = 0; i < nb; i++) bitbuf[i >> 2] |= (uint32_t)hb[i] << (24u - 8u * (i & 3u));
+		if(bs_hint == 6) hb(n - 1u);
+		else if(bs_hint == 7) { hb((n - 1u) >> 8); hb(n - 1u); }
+		if(sr_hint == 12) hb(c.rate / 1000u);
+		else if(sr_hint == 13) { hb(c.rate >> 8); hb(c.rate); }
+		else if(sr_hint == 14) { hb((c.rate / 10u) >> 8); hb(c.rate / 10u); }
+		hb(crc);
+		sh.hdr_bytes = nb;
 	}
 	__syncthreads();
-	{
-		const uint32_t hdr_bits = sh.wave_tot[0] * 8u;
-		__syncthreads();
-		flush_words(bitbuf, hdr_bits, slot_words, sh);
-	}
+	flush_words(bitbuf, sh.hdr_bytes * 8u, slot_words, sh, w, segw);
 
 	const uint32_t assignment = sh.assignment;
 	const uint32_t nsub = c.channels;
-	const uint32_t S = (n + 255u) / 256u; // samples per thread
+	const uint32_t nrounds = (n + 256u * CH - 1u) / (256u * CH);
 
 	for(uint32_t sc = 0; sc < nsub; sc++) {
 		uint32_t sig = sc;
@@ -243,104 +259,139 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		               rice2 = FA_WIN_RICE2(h0), wasted = FA_WIN_WASTED(h0), wide = FA_WIN_WIDE(h0);
 
 		// stage the signal and the winner's parameters
-		for(uint32_t i = tid; i < n; i += 256) xs[pk_xs_idx((int32_t)i)] = fa_signal(pcm, c, sig, base + i) >> wasted;
+		{
+			const uint32_t nup = (n + CH - 1u) & ~(CH - 1u);
+			for(uint32_t i = tid; i < nup; i += 256) xs[xs_idx((int32_t)i)] = (i < n) ? (fa_signal(pcm, c, sig, base + i) >> wasted) : 0;
+		}
 		if(tid < FLACAMD_MAX_LPC_ORDER) sh.q[tid] = win->q[tid];
 		if(type >= FA_SUB_FIXED) for(uint32_t p = tid; p < (1u << po); p += 256) sh.k[p] = win->k[p];
 		__syncthreads();
 
-		const uint32_t carry = sh.carry_bits;
 		// bits of the subframe head: type byte, wasted-bits unary, warm-up, lpc parameters, coding method + partition order
-		uint32_t head_bits = 8u + (wasted ? wasted : 0u);
+		uint32_t head_bits = 8u + wasted;
 		if(type == FA_SUB_FIXED) head_bits += order * sbps + 6u;
 		else if(type == FA_SUB_LPC) head_bits += order * sbps + 9u + order * prec + 6u;
 		const uint32_t plen = rice2 ? 5u : 4u;
 		const uint32_t dps = n >> po;
+		const uint32_t carry = sh.carry_bits;
+		const uint32_t smask = sbps < 32u ? (1u << sbps) - 1u : 0xffffffffu;
 
-		const uint32_t i0 = tid * S, i1 = (i0 + S < n) ? i0 + S : n;
-		uint32_t mybits = 0;
-		if(type == FA_SUB_CONSTANT) mybits = (tid == 0) ? sbps : 0u;
-		else if(type == FA_SUB_VERBATIM) mybits = (i1 > i0) ? (i1 - i0) * sbps : 0u;
-		else {
-			for(uint32_t i = (i0 > order ? i0 : order); i < i1; i++) {
-				const uint32_t p = po ? i / dps : 0u, k = sh.k[p];
-				const int32_t r = residual_at(xs, i, type, order, shift, wide, sh.q);
-				const uint32_t u = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
-				mybits += (u >> k) + 1u + k;
-				if(i == (p * dps > order ? p * dps : order)) mybits += plen; // first residual of its partition
-			}
-		}
-		uint32_t body_bits;
-		const uint32_t myoff = block_exscan(mybits, sh, body_bits);
-		const uint32_t sub_bits = head_bits + body_bits;
-		if(carry + sub_bits > cap_bits) { // cannot happen for estimates that did not wrap; never write past the buffer
-			if(tid == 0) { sh.overflow = 1; atomicOr(w.status, 1u); }
-			__syncthreads();
-			break;
-		}
-
-		// ---- write the head (one lane; a few dozen tokens)
-		if(tid == 0) {
-			uint32_t pos = carry;
+		// ---- head (one lane; a few dozen tokens)
+		if(tid == 0 && carry + head_bits <= cap_bits) {
+			BitRun br; br.begin(bitbuf, carry);
 			uint32_t tb;
 			switch(type) { // stream_encoder_framing.c:371, :383, :421, :468
 			case FA_SUB_CONSTANT: tb = 0x00; break; case FA_SUB_VERBATIM: tb = 0x02; break;
 			case FA_SUB_FIXED: tb = 0x10u | (order << 1); break; default: tb = 0x40u | ((order - 1u) << 1); break;
 			}
-			put_bits(bitbuf, pos, tb | (wasted ? 1u : 0u), 8); pos += 8;
-			if(wasted) { pos += wasted - 1u; put_bits(bitbuf, pos, 1u, 1); pos += 1; }
+			br.put(tb | (wasted ? 1u : 0u), 8);
+			if(wasted) { br.zeros(wasted - 1u); br.put(1u, 1); }
 			if(type >= FA_SUB_FIXED) {
-				for(uint32_t i = 0; i < order; i++) { put_bits(bitbuf, pos, (uint32_t)xs[pk_xs_idx((int32_t)i)], sbps); pos += sbps; }
+				for(uint32_t i = 0; i < order; i++) br.put((uint32_t)xs[xs_idx((int32_t)i)] & smask, sbps);
 				if(type == FA_SUB_LPC) {
-					put_bits(bitbuf, pos, prec - 1u, 4); pos += 4;
-					put_bits(bitbuf, pos, shift, 5); pos += 5;
-					for(uint32_t i = 0; i < order; i++) { put_bits(bitbuf, pos, (uint32_t)sh.q[i], prec); pos += prec; }
+					br.put(prec - 1u, 4); br.put(shift, 5);
+					for(uint32_t i = 0; i < order; i++) br.put((uint32_t)sh.q[i] & ((1u << prec) - 1u), prec);
 				}
-				put_bits(bitbuf, pos, rice2, 2); pos += 2;
-				put_bits(bitbuf, pos, po, 4); pos += 4;
+				br.put(rice2, 2); br.put(po, 4);
 			}
+			br.end();
 		}
-		// ---- write the body
-		{
-			uint32_t pos = carry + head_bits + myoff;
-			if(type == FA_SUB_CONSTANT) { if(tid == 0) put_bits(bitbuf, pos, (uint32_t)xs[pk_xs_idx(0)], sbps); }
-			else if(type == FA_SUB_VERBATIM) { for(uint32_t i = i0; i < i1; i++) { put_bits(bitbuf, pos, (uint32_t)xs[pk_xs_idx((int32_t)i)], sbps); pos += sbps; } }
-			else {
-				for(uint32_t i = (i0 > order ? i0 : order); i < i1; i++) {
-					const uint32_t p = po ? i / dps : 0u, k = sh.k[p];
-					if(i == (p * dps > order ? p * dps : order)) { put_bits(bitbuf, pos, k, plen); pos += plen; }
-					const int32_t r = residual_at(xs, i, type, order, shift, wide, sh.q);
-					const uint32_t u = ((uint32_t)r << 1) ^ (uint32_t)(r >> 31);
-					pos += u >> k;                                               // unary zeros
-					put_bits(bitbuf, pos, (1u << k) | (u & ((1u << k) - 1u)), k + 1u); // stop bit + k low bits
-					pos += k + 1u;
+
+		uint32_t bitpos = carry + head_bits;
+		bool ovf = bitpos > cap_bits;
+		for(uint32_t r = 0; r < nrounds && !ovf; r++) {
+			const uint32_t i0 = (r * 256u + tid) * CH;
+			uint32_t u[CH];       // folded residual / verbatim sample bits
+			uint32_t meta[CH];    // bit length of the token; bit 31: a partition parameter precedes it; bits 24..28: k
+			uint32_t mybits = 0;
+#pragma unroll
+			for(int s = 0; s < CH; s++) { u[s] = 0; meta[s] = 0; }
+			if(i0 < n) {
+				if(type == FA_SUB_CONSTANT) { if(i0 == 0) { u[0] = (uint32_t)xs[xs_idx(0)] & smask; meta[0] = sbps; mybits = sbps; } }
+				else if(type == FA_SUB_VERBATIM) {
+#pragma unroll
+					for(int s = 0; s < CH; s++) if(i0 + (uint32_t)s < n) { u[s] = (uint32_t)xs[xs_idx((int32_t)(i0 + s))] & smask; meta[s] = sbps; mybits += sbps; }
+				}
+				else {
+					int32_t res[CH];
+					if(order <= HIST) {
+						int32_t xw[HIST + CH];
+#pragma unroll
+						for(int j = 0; j < HIST + CH; j++) xw[j] = xs[xs_idx((int32_t)i0 - HIST + j)];
+						auto keep = [&](int s, int32_t rv, int) { res[s] = rv; };
+						if(type == FA_SUB_FIXED) fixed_each_dispatch(order, xw, keep);
+						else {
+							int32_t q[HIST];
+#pragma unroll
+							for(int j = 0; j < HIST; j++) q[j] = sh.q[j];
+							if(wide) lpc_each_dispatch<MAC_WIDE>(order, xw, q, shift, keep);
+							else if(sbps <= 24) lpc_each_dispatch<MAC_I24>(order, xw, q, shift, keep);
+							else lpc_each_dispatch<MAC_I32>(order, xw, q, shift, keep);
+						}
+					}
+					else {
+#pragma unroll
+						for(int s = 0; s < CH; s++) { const uint32_t i = i0 + (uint32_t)s; res[s] = (i >= order && i < n) ? residual_generic(xs, i, true, order, shift, wide, sh.q) : 0; }
+					}
+					// partition walk: sample i lies in partition i / dps (partition 0 starts at `order`)
+					uint32_t p = po ? i0 / dps : 0u;
+					uint32_t next = po ? (p + 1u) * dps : 0xffffffffu;
+					uint32_t kcur = sh.k[p];
+#pragma unroll
+					for(int s = 0; s < CH; s++) {
+						const uint32_t i = i0 + (uint32_t)s;
+						if(i == next) { p++; next += dps; kcur = sh.k[p]; }
+						if(i >= order && i < n) {
+							const uint32_t uu = ((uint32_t)res[s] << 1) ^ (uint32_t)(res[s] >> 31);
+							const bool first = (i == (p ? p * dps : order));
+							const uint32_t len = (uu >> kcur) + 1u + kcur;
+							u[s] = uu; meta[s] = len | (kcur << 24) | (first ? 0x80000000u : 0u);
+							mybits += len + (first ? plen : 0u);
+						}
+					}
 				}
 			}
+			uint32_t round_bits;
+			const uint32_t myoff = block_exscan(mybits, sh, round_bits);
+			if(bitpos + round_bits > cap_bits) { ovf = true; break; }
+			if(mybits) {
+				BitRun br; br.begin(bitbuf, bitpos + myoff);
+				if(type <= FA_SUB_VERBATIM) {
+#pragma unroll
+					for(int s = 0; s < CH; s++) if(meta[s]) br.put(u[s], meta[s]);
+				}
+				else {
+#pragma unroll
+					for(int s = 0; s < CH; s++) if(meta[s]) {
+						const uint32_t k = (meta[s] >> 24) & 31u;
+						if(meta[s] & 0x80000000u) br.put(k, plen);
+						br.zeros(u[s] >> k);                                         // unary part
+						br.put((1u << k) | (u[s] & ((1u << k) - 1u)), k + 1u);      // stop bit + k low bits
+					}
+				}
+				br.end();
+			}
+			bitpos += round_bits;
 		}
-		flush_words(bitbuf, carry + sub_bits, slot_words, sh);
+		if(ovf) { // cannot happen for estimates that did not wrap; never write past the buffer
+			if(tid == 0) { sh.overflow = 1; atomicOr(w.status, 1u); }
+			__syncthreads();
+			break;
+		}
+		flush_words(bitbuf, bitpos, slot_words, sh, w, segw);
 	}
 
 	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905)
 	if(sh.overflow) { if(tid == 0) w.frame_bytes[f] = 0; return; }
-	const uint32_t tail_bits = sh.carry_bits, tail_bytes = (tail_bits + 7u) >> 3;
-	const uint32_t body_bytes = sh.words_out * 4u + tail_bytes;
-	if(tid < tail_bytes) slot[sh.words_out * 4u + tid] = (uint8_t)(bitbuf[0] >> (24u - 8u * tid));
-	__syncthreads();
-	{
-		// each thread: CRC of its segment, then * x^(8 * bytes after the segment)
-		const uint32_t seg = ((body_bytes + 255u) / 256u + 3u) & ~3u;
-		const uint32_t b0 = tid * seg, b1 = (b0 + seg < body_bytes) ? b0 + seg : body_bytes;
-		uint32_t crc = 0;
-		if(b0 < body_bytes) {
-			for(uint32_t b = b0; b < b1; b++) crc = crc16_byte(crc, slot[b]);
-			crc = gf16_mul(crc, gf16_xpow8(body_bytes - b1));
-		}
-#pragma unroll
-		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
-		if((tid & 63u) == 0) atomicXor(&sh.crc, crc);
-	}
-	__syncthreads();
 	if(tid == 0) {
-		const uint32_t crc = sh.crc;
+		const uint32_t tail_bits = sh.carry_bits, tail_bytes = (tail_bits + 7u) >> 3;
+		const uint32_t body_bytes = sh.words_out * 4u + tail_bytes;
+		uint32_t crc = sh.crc;
+		for(uint32_t i = 0; i < tail_bytes; i++) {
+			const uint32_t byte = (bitbuf[0] >> (24u - 8u * i)) & 0xffu;
+			slot[sh.words_out * 4u + i] = (uint8_t)byte;
+			crc = ((crc << 8) & 0xffffu) ^ sh.crc4[0][(crc >> 8) ^ byte];
+		}
 		slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc;
 		w.frame_bytes[f] = body_bytes + 2u;
 	}
@@ -407,7 +458,7 @@ extern "C" size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out)
 	const size_t bits = (size_t)c->N * (maxbps + 1u) + 8u + 32u + 32u * (maxbps + 15u) + 64u + 64u;
 	const uint32_t words = (uint32_t)((bits + 31u) / 32u) + 4u;
 	if(bitbuf_words_out) *bitbuf_words_out = words;
-	return (((size_t)c->N + 32u) * 4u + (size_t)words * 4u + 15u) & ~(size_t)15u;
+	return ((size_t)xs_words_for(c->N) * 4u + (size_t)words * 4u + 15u) & ~(size_t)15u;
 }
 
 extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)

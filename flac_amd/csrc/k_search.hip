@@ -23,96 +23,7 @@
 // This is integer work bound by VALU issue, not by HBM: ~(order+5) lane-ops per sample
 // per LPC candidate.
 #include "engine_types.h"
-
-#define CH 16          // samples per register chunk
-#define HIST 12        // history kept in registers: orders above 12 take the generic path
-
-// LDS index of signal sample i (i >= -32): one pad word per 16 so that lanes reading
-// windows at a 16-sample stride hit distinct banks.
-__device__ __forceinline__ uint32_t xs_idx(int32_t i) { const uint32_t u = (uint32_t)(i + 32); return u + (u >> 4); }
-
-__device__ __forceinline__ uint32_t abs_u32(int32_t r) { return (uint32_t)(r < 0 ? 0u - (uint32_t)r : (uint32_t)r); }
-
-enum { MAC_I24 = 0, MAC_I32 = 1, MAC_WIDE = 2 };
-
-// d = a * b + c on the 24-bit multiplier (full rate); the low 32 bits of the sum are exact
-// for |a|, |b| < 2^23.  Written as asm so that the chain stays one instruction per tap
-// (the compiler otherwise splits it into two multiplies and a three-operand add).
-__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)
-{
-	int32_t d;
-	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-	return d;
-}
-
-// |residual| sums of one 16-sample chunk for an order-P predictor.  `head` collects the
-// first P samples of the chunk (they are warm-up samples, not residuals, when the chunk
-// is the first of the frame), `tail` the rest.
-template<int P, int MODE, typename SUM>
-__device__ __forceinline__ void lpc_chunk(const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, SUM &head, SUM &tail)
-{
-	SUM h = 0, t = 0;
-#pragma unroll
-	for(int s = 0; s < CH; s++) {
-		int32_t pred;
-		if(MODE == MAC_WIDE) {
-			long long acc = 0;
-#pragma unroll
-			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
-			pred = (int32_t)(acc >> shift);
-		}
-		else if(MODE == MAC_I24) {
-			int32_t acc = 0;
-#pragma unroll
-			for(int j = 0; j < P; j++) acc = mad24(q[j], xw[HIST + s - 1 - j], acc); // low 32 bits of the sum: same wrap as lpc.c:296
-			pred = acc >> shift;
-		}
-		else {
-			uint32_t acc = 0;
-#pragma unroll
-			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
-			pred = (int32_t)acc >> shift;
-		}
-		const uint32_t m = abs_u32((int32_t)((uint32_t)xw[HIST + s] - (uint32_t)pred));
-		if(s < P) h += m; else t += m;
-	}
-	head = h; tail = t;
-}
-
-template<int MODE, typename SUM>
-__device__ __forceinline__ void lpc_chunk_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, SUM &head, SUM &tail)
-{
-	switch(order) {
-	case 1: lpc_chunk<1, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 2: lpc_chunk<2, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 3: lpc_chunk<3, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 4: lpc_chunk<4, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 5: lpc_chunk<5, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 6: lpc_chunk<6, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 7: lpc_chunk<7, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 8: lpc_chunk<8, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 9: lpc_chunk<9, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 10: lpc_chunk<10, MODE, SUM>(xw, q, shift, head, tail); break;
-	case 11: lpc_chunk<11, MODE, SUM>(xw, q, shift, head, tail); break;
-	default: lpc_chunk<12, MODE, SUM>(xw, q, shift, head, tail); break;
-	}
-}
-
-// k-th difference (fixed.c:352-393) of the chunk, 32-bit wrapping
-template<int K, typename SUM>
-__device__ __forceinline__ void fixed_chunk(const int32_t (&xw)[HIST + CH], SUM &head, SUM &tail)
-{
-	SUM h = 0, t = 0;
-#pragma unroll
-	for(int s = 0; s < CH; s++) {
-		const uint32_t a = (uint32_t)xw[HIST + s], b = (uint32_t)xw[HIST + s - 1], c = (uint32_t)xw[HIST + s - 2], d = (uint32_t)xw[HIST + s - 3], e = (uint32_t)xw[HIST + s - 4];
-		uint32_t r;
-		if(K == 0) r = a; else if(K == 1) r = a - b; else if(K == 2) r = a - 2u*b + c; else if(K == 3) r = a - 3u*b + 3u*c - d; else r = a - 4u*b + 6u*c - 4u*d + e;
-		const uint32_t m = abs_u32((int32_t)r);
-		if(s < K) h += m; else t += m;
-	}
-	head = h; tail = t;
-}
+#include "residual.h"
 
 // format.c:548-561
 __device__ __forceinline__ uint32_t limit_po(uint32_t limit, uint32_t blocksize, uint32_t order)
@@ -149,7 +60,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	const bool fast = ((n & (CH - 1)) == 0) && ((dps0 & (CH - 1)) == 0);
 
 	// LDS carve-up
-	const uint32_t xs_words = ((c.N + 32u) * 17u) / 16u + 17u;
+	const uint32_t xs_words = xs_words_for(c.N);
 	int32_t *xs = (int32_t*)lds_raw;
 	// |residual| sums of every partition at every order: row ci holds the finest order first
 	// (parts0 entries), then each coarser order, 2*parts0 - 1 entries in all
@@ -209,23 +120,16 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr);
 					SUM head = 0, tail = 0;
-					if(FA_CAND_KIND(hdr) == 0) {
-						switch(order) {
-						case 0: fixed_chunk<0, SUM>(xw, head, tail); break;
-						case 1: fixed_chunk<1, SUM>(xw, head, tail); break;
-						case 2: fixed_chunk<2, SUM>(xw, head, tail); break;
-						case 3: fixed_chunk<3, SUM>(xw, head, tail); break;
-						default: fixed_chunk<4, SUM>(xw, head, tail); break;
-						}
-					}
+					auto accum = [&](int sidx, int32_t rv, int P) { const uint32_t m = abs_u32(rv); if(sidx < P) head += m; else tail += m; };
+					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, accum);
 					else if(order <= HIST) {
 						int32_t q[HIST];
 #pragma unroll
 						for(int j = 0; j < HIST; j++) q[j] = cq[ci * HIST + j];
 						const uint32_t shift = FA_CAND_SHIFT(hdr);
-						if(FA_CAND_WIDE(hdr)) lpc_chunk_dispatch<MAC_WIDE, SUM>(order, xw, q, shift, head, tail);
-						else if(bps <= 24) lpc_chunk_dispatch<MAC_I24, SUM>(order, xw, q, shift, head, tail);
-						else lpc_chunk_dispatch<MAC_I32, SUM>(order, xw, q, shift, head, tail);
+						if(FA_CAND_WIDE(hdr)) lpc_each_dispatch<MAC_WIDE>(order, xw, q, shift, accum);
+						else if(bps <= 24) lpc_each_dispatch<MAC_I24>(order, xw, q, shift, accum);
+						else lpc_each_dispatch<MAC_I32>(order, xw, q, shift, accum);
 					}
 					else continue; // high orders: generic pass below
 					const SUM v = tail + (chunk == 0 ? (SUM)0 : head);
@@ -400,7 +304,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 
 extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 {
-	const size_t xs_words = ((size_t)(c->N + 32u) * 17u) / 16u + 17u;
+	const size_t xs_words = xs_words_for(c->N);
 	const size_t parts_cap = (size_t)1 << (c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER);
 	size_t b = (xs_words * 4u + 15u) & ~(size_t)15u;
 	b += (size_t)cg * 2u * parts_cap * 8u;  // psum, all partition orders

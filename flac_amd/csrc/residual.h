@@ -1,0 +1,132 @@
+// Register-window residual evaluation shared by the search and pack kernels.
+//
+// A thread holds CH consecutive samples of a signal plus HIST samples of history in
+// registers (xw[HIST + s] is sample s of the chunk) and evaluates a predictor on all CH
+// samples with fully unrolled code: coefficients are wave-uniform, every tap is one VALU
+// instruction.  Orders above HIST take the callers' generic per-sample path.
+//
+// Restates FLAC__fixed_compute_residual (fixed.c:352-393),
+// FLAC__lpc_compute_residual_from_qlp_coefficients (lpc.c:265-529, 32-bit wrapping sum) and
+// ..._wide (lpc.c:531-791, 64-bit sum); which of the two applies is the reference's choice
+// (stream_encoder.c:3597-3603), made by the model kernel and carried in the candidate.
+#pragma once
+#include <stdint.h>
+
+#define CH 16
+#define HIST 12
+
+enum { MAC_I24 = 0, MAC_I32 = 1, MAC_WIDE = 2 };
+
+// LDS index of signal sample i (i >= -32): one pad word per 16 samples so that lanes
+// reading windows at a 16-sample stride hit distinct banks.
+__device__ __forceinline__ uint32_t xs_idx(int32_t i) { const uint32_t u = (uint32_t)(i + 32); return u + (u >> 4); }
+// words needed for a signal of n samples in that layout
+__host__ __device__ inline uint32_t xs_words_for(uint32_t n) { return ((n + 32u) * 17u) / 16u + 17u; }
+
+__device__ __forceinline__ uint32_t abs_u32(int32_t r) { return (uint32_t)(r < 0 ? 0u - (uint32_t)r : (uint32_t)r); }
+
+// d = a * b + c on the 24-bit multiplier; the low 32 bits are exact for |a|, |b| < 2^23.
+// Written as asm so that a predictor stays one instruction per tap (the compiler otherwise
+// splits the chain into two multiplies and a three-operand add per pair of taps).
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)
+{
+	int32_t d;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+
+// f(s, r, P): residual r of chunk sample s under an order-P predictor
+template<int P, int MODE, class F>
+__device__ __forceinline__ void lpc_each(const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < CH; s++) {
+		int32_t pred;
+		if(MODE == MAC_WIDE) {
+			long long acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+			pred = (int32_t)(acc >> shift);
+		}
+		else if(MODE == MAC_I24) {
+			int32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc = mad24(q[j], xw[HIST + s - 1 - j], acc); // low 32 bits of the sum: the wrap of lpc.c:296
+			pred = acc >> shift;
+		}
+		else {
+			uint32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
+			pred = (int32_t)acc >> shift;
+		}
+		f(s, (int32_t)((uint32_t)xw[HIST + s] - (uint32_t)pred), P);
+	}
+}
+
+template<int MODE, class F>
+__device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+	switch(order) {
+	case 1: lpc_each<1, MODE>(xw, q, shift, f); break;
+	case 2: lpc_each<2, MODE>(xw, q, shift, f); break;
+	case 3: lpc_each<3, MODE>(xw, q, shift, f); break;
+	case 4: lpc_each<4, MODE>(xw, q, shift, f); break;
+	case 5: lpc_each<5, MODE>(xw, q, shift, f); break;
+	case 6: lpc_each<6, MODE>(xw, q, shift, f); break;
+	case 7: lpc_each<7, MODE>(xw, q, shift, f); break;
+	case 8: lpc_each<8, MODE>(xw, q, shift, f); break;
+	case 9: lpc_each<9, MODE>(xw, q, shift, f); break;
+	case 10: lpc_each<10, MODE>(xw, q, shift, f); break;
+	case 11: lpc_each<11, MODE>(xw, q, shift, f); break;
+	default: lpc_each<12, MODE>(xw, q, shift, f); break;
+	}
+}
+
+// k-th difference, 32-bit wrapping
+template<int K, class F>
+__device__ __forceinline__ void fixed_each(const int32_t (&xw)[HIST + CH], F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < CH; s++) {
+		const uint32_t a = (uint32_t)xw[HIST + s], b = (uint32_t)xw[HIST + s - 1], c = (uint32_t)xw[HIST + s - 2], d = (uint32_t)xw[HIST + s - 3], e = (uint32_t)xw[HIST + s - 4];
+		uint32_t r;
+		if(K == 0) r = a; else if(K == 1) r = a - b; else if(K == 2) r = a - 2u*b + c; else if(K == 3) r = a - 3u*b + 3u*c - d; else r = a - 4u*b + 6u*c - 4u*d + e;
+		f(s, (int32_t)r, K);
+	}
+}
+
+template<class F>
+__device__ __forceinline__ void fixed_each_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], F &&f)
+{
+	switch(order) {
+	case 0: fixed_each<0>(xw, f); break;
+	case 1: fixed_each<1>(xw, f); break;
+	case 2: fixed_each<2>(xw, f); break;
+	case 3: fixed_each<3>(xw, f); break;
+	default: fixed_each<4>(xw, f); break;
+	}
+}
+
+// generic residual of sample i (i >= order) read from the LDS copy of the signal; q is
+// any pointer to the coefficients
+__device__ __forceinline__ int32_t residual_generic(const int32_t *xs, uint32_t i, bool lpc, uint32_t order, uint32_t shift, uint32_t wide, const int32_t *q)
+{
+	if(!lpc) {
+		const uint32_t a = (uint32_t)xs[xs_idx((int32_t)i)], b = (uint32_t)xs[xs_idx((int32_t)i - 1)], c = (uint32_t)xs[xs_idx((int32_t)i - 2)],
+		               d = (uint32_t)xs[xs_idx((int32_t)i - 3)], e = (uint32_t)xs[xs_idx((int32_t)i - 4)];
+		return (int32_t)(order == 0 ? a : order == 1 ? a - b : order == 2 ? a - 2u*b + c : order == 3 ? a - 3u*b + 3u*c - d : a - 4u*b + 6u*c - 4u*d + e);
+	}
+	int32_t pred;
+	if(wide) {
+		long long acc = 0;
+		for(uint32_t j = 0; j < order; j++) acc += (long long)q[j] * (long long)xs[xs_idx((int32_t)(i - 1u - j))];
+		pred = (int32_t)(acc >> shift);
+	}
+	else {
+		uint32_t acc = 0;
+		for(uint32_t j = 0; j < order; j++) acc += (uint32_t)q[j] * (uint32_t)xs[xs_idx((int32_t)(i - 1u - j))];
+		pred = (int32_t)acc >> shift;
+	}
+	return (int32_t)((uint32_t)xs[xs_idx((int32_t)i)] - (uint32_t)pred);
+}
