@@ -7,15 +7,97 @@
 // the Rice parameter suggested for partition order 0) is a discontinuous function of
 // those floats, so the sums are kept bit-identical here: ONE LANE PER SIGNAL owns all
 // `lag` running sums of that signal and walks its samples in order with unfused
-// multiply and add.  A wave therefore covers 64 signals (16 stereo frames); the chip
-// is filled by the number of frames in the batch, not by splitting a sum.
+// multiply and add (an MFMA or tree reduction would change the rounding).  A wave covers
+// 64 signals (16 stereo frames); the chip is filled by the number of frames in the batch.
 //
-// Each lane reads its own signal directly from the interleaved PCM (16 samples per step,
-// straight into registers; the samples of one frame are shared by its 4 signals through
-// L1/L2), applies the wasted-bit shift and the window (uniform index: scalar loads), and
-// keeps the last `lag` windowed samples in a register shift chain.  No LDS.
+// Each lane streams its own signal straight from the interleaved PCM into registers,
+// 16 samples per step with the next step's loads already in flight (the 4 signals of a
+// frame share the same bytes through L1/L2), applies the wasted-bit shift and the window
+// (wave-uniform index: scalar loads) and keeps the last `lag` windowed samples in a
+// register delay line.  No LDS.  Cost: 2*lag + ~8 VALU instructions per sample per lane.
 #include "engine_types.h"
 
+#define AC_STEP 16
+
+// 16 raw wide samples of a 16-bit stereo stream: one dword (left | right << 16) each
+struct Raw16 { uint4 v[4]; };
+
+__device__ __forceinline__ uint32_t raw_get(const Raw16 &r, int j)
+{
+	const uint4 &q = r.v[j >> 2];
+	return (j & 3) == 0 ? q.x : (j & 3) == 1 ? q.y : (j & 3) == 2 ? q.z : q.w;
+}
+
+// Fast path: 16-bit stereo, mid/side analysis (signals L, R, M, S), blocksize a multiple of 16.
+template<int LAG>
+__global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t g = blockIdx.x * 64u + lane;
+	const bool active = g < c.G;
+	const uint32_t gg = active ? g : c.G - 1u;
+	const uint32_t f = gg >> 2, s = gg & 3u;
+	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
+	const uint32_t wasted = w.wasted[gg];
+	const uint32_t f0 = (blockIdx.x * 64u) >> 2;
+	const uint32_t nloop = (f0 + 1 == c.F) ? c.last_n : c.N;
+	// signal = (ca * left + cb * right) >> (cs + wasted): L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058)
+	const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
+	const uint32_t sh = wasted + (s == 2u ? 1u : 0u);
+
+	auto load16 = [&](uint32_t i0) {
+		Raw16 r;
+		if(i0 + AC_STEP <= n) {
+			const uint4 *q = (const uint4*)(p + i0);
+			r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+		}
+		else { // tail of a short last block: never read past the end of the stream
+			uint32_t t[AC_STEP];
+#pragma unroll
+			for(int j = 0; j < AC_STEP; j++) t[j] = (i0 + (uint32_t)j < n) ? p[i0 + j] : 0u;
+#pragma unroll
+			for(int j = 0; j < 4; j++) r.v[j] = make_uint4(t[4*j], t[4*j+1], t[4*j+2], t[4*j+3]);
+		}
+		return r;
+	};
+
+	for(uint32_t a = 0; a < c.num_apod; a++) {
+		const float *__restrict__ win = w.window + (size_t)a * c.N;
+		float acc[LAG], hist[LAG];
+#pragma unroll
+		for(int l = 0; l < LAG; l++) { acc[l] = 0.0f; hist[l] = 0.0f; }
+		Raw16 nxt = load16(0);
+		for(uint32_t i0 = 0; i0 < nloop; i0 += AC_STEP) {
+			const Raw16 cur = nxt;
+			if(i0 + AC_STEP < nloop) nxt = load16(i0 + AC_STEP);
+#pragma unroll
+			for(int j = 0; j < AC_STEP; j++) {
+				const uint32_t lr = raw_get(cur, j);
+				const int32_t l = (int32_t)(int16_t)(lr & 0xffffu), r = (int32_t)lr >> 16;
+				const int32_t x = (ca * l + cb * r) >> sh;
+				const uint32_t i = i0 + (uint32_t)j;
+				// lpc.c:60; samples past the end of a short block are zero (raw is zero there and the
+				// window index is clamped to stay inside the table)
+				const float d = __fmul_rn((float)x, win[i]);
+#pragma unroll
+				for(int k = LAG - 1; k > 0; k--) hist[k] = hist[k-1];
+				hist[0] = d;
+				// autoc[l] += d[m-l] * d[m]  (same products, same order as lpc.c:100-109; the
+				// zero-filled history adds +-0 for m < l, which leaves the sum unchanged)
+#pragma unroll
+				for(int k = 0; k < LAG; k++) acc[k] = __fadd_rn(acc[k], __fmul_rn(hist[k], d));
+			}
+		}
+		if(active) {
+#pragma unroll
+			for(int k = 0; k < LAG; k++)
+				if((uint32_t)k < c.lag) w.autoc[((size_t)a * c.lag + k) * c.G + g] = acc[k];
+		}
+	}
+}
+
+// Generic path: any channel count / sample format / blocksize.
 template<int LAG>
 __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w)
 {
@@ -36,31 +118,30 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 		float acc[LAG], hist[LAG];
 #pragma unroll
 		for(int l = 0; l < LAG; l++) { acc[l] = 0.0f; hist[l] = 0.0f; }
-
-		for(uint32_t i0 = 0; i0 < nloop; i0 += 16) {
-			float d[16];
+		int32_t nxt[4];
 #pragma unroll
-			for(int j = 0; j < 16; j++) {
+		for(int j = 0; j < 4; j++) nxt[j] = ((uint32_t)j < n) ? fa_signal(pcm, c, s, base + j) : 0;
+		for(uint32_t i0 = 0; i0 < nloop; i0 += 4) {
+			int32_t cur[4];
+#pragma unroll
+			for(int j = 0; j < 4; j++) cur[j] = nxt[j];
+#pragma unroll
+			for(int j = 0; j < 4; j++) { const uint32_t i = i0 + 4u + (uint32_t)j; nxt[j] = (i < n) ? fa_signal(pcm, c, s, base + i) : 0; }
+#pragma unroll
+			for(int j = 0; j < 4; j++) {
 				const uint32_t i = i0 + (uint32_t)j;
-				float v = 0.0f;
-				if(i < n) v = __fmul_rn((float)(fa_signal(pcm, c, s, base + i) >> wasted), win[i]); // lpc.c:60
-				d[j] = v;
-			}
+				const float d = __fmul_rn((float)(cur[j] >> wasted), win[i < c.N ? i : c.N - 1u]); // lpc.c:60
 #pragma unroll
-			for(int j = 0; j < 16; j++) {
+				for(int k = LAG - 1; k > 0; k--) hist[k] = hist[k-1];
+				hist[0] = d;
 #pragma unroll
-				for(int l = LAG - 1; l > 0; l--) hist[l] = hist[l-1];
-				hist[0] = d[j];
-				// autoc[l] += d[m-l] * d[m]  (same products, same order as lpc.c:100-109;
-				// the zero-filled history adds +-0 for m < l, which leaves the sum unchanged)
-#pragma unroll
-				for(int l = 0; l < LAG; l++) acc[l] = __fadd_rn(acc[l], __fmul_rn(hist[l], d[j]));
+				for(int k = 0; k < LAG; k++) acc[k] = __fadd_rn(acc[k], __fmul_rn(hist[k], d));
 			}
 		}
 		if(active) {
 #pragma unroll
-			for(int l = 0; l < LAG; l++)
-				if((uint32_t)l < c.lag) w.autoc[((size_t)a * c.lag + l) * c.G + g] = acc[l];
+			for(int k = 0; k < LAG; k++)
+				if((uint32_t)k < c.lag) w.autoc[((size_t)a * c.lag + k) * c.G + g] = acc[k];
 		}
 	}
 }
@@ -68,7 +149,15 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 extern "C" void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
 	const dim3 grid((c->G + 63u) / 64u), block(64);
-	if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_kernel<9>, grid, block, 0, st, pcm, *c, *w);
-	else if(c->lag <= 13) hipLaunchKernelGGL(fa_autoc_kernel<13>, grid, block, 0, st, pcm, *c, *w);
-	else hipLaunchKernelGGL(fa_autoc_kernel<33>, grid, block, 0, st, pcm, *c, *w);
+	const bool ms16 = c->midside && c->pcm_format == FLACAMD_PCM_S16 && (c->N % AC_STEP) == 0 && ((uintptr_t)pcm % 16u) == 0;
+	if(ms16) {
+		if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_ms16_kernel<9>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		else if(c->lag <= 13) hipLaunchKernelGGL(fa_autoc_ms16_kernel<13>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		else hipLaunchKernelGGL(fa_autoc_ms16_kernel<33>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+	}
+	else {
+		if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_kernel<9>, grid, block, 0, st, pcm, *c, *w);
+		else if(c->lag <= 13) hipLaunchKernelGGL(fa_autoc_kernel<13>, grid, block, 0, st, pcm, *c, *w);
+		else hipLaunchKernelGGL(fa_autoc_kernel<33>, grid, block, 0, st, pcm, *c, *w);
+	}
 }
