@@ -1,0 +1,560 @@
+// Frame-parallel FLAC decoder for gfx950.
+//
+// Replaces, over a byte range of frames held in device memory:
+//   frame_sync_                         stream_decoder.c:1947-2000   (scan for 0xFF 0xF8|0xF9)
+//   read_frame_header_                  :2147-2454                   (field checks, UTF-8 number, CRC-8)
+//   read_frame_ / read_subframe_*       :2002-2145, :2456-2719
+//   read_residual_partitioned_rice_     :2721-2777  + FLAC__bitreader_read_rice_signed_block (bitreader.c:814-)
+//   FLAC__fixed_restore_signal          fixed.c:395-435
+//   FLAC__lpc_restore_signal{,_wide}    lpc.c:795-1321 (selector stream_decoder.c:2682-2692)
+//   channel decorrelation, CRC-16 check stream_decoder.c:2067-2118
+//
+// A FLAC frame carries no length, so frame boundaries are not known before decoding.  The
+// reference decodes serially and resynchronises on errors; here every position that passes
+// the header checks (sync code, legal fields, CRC-8) is a CANDIDATE and all candidates are
+// decoded speculatively in parallel, one lane per candidate (Rice decoding and the
+// prediction recurrence are serial inside a subframe).  A candidate is a frame iff its
+// CRC-16 holds; the accepted frames must then tile the byte range exactly (each starts
+// where the previous one ended), which is checked on the device.  False candidates
+// (about one per 2^23 bytes of compressed audio) cost one wasted lane each.
+#include "engine_types.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FD_SCAN_BYTES 4096u   // bytes scanned per workgroup
+
+struct FdCfg {
+	uint32_t channels, bps, max_bs, max_frames;
+	uint64_t nbytes;
+	uint32_t nscan_wg;
+	uint32_t crc_seg_bytes;
+	uint32_t pcm_format;
+	uint64_t pcm_cap;
+};
+
+struct FdWork {
+	uint32_t *wg_count;     // [nscan_wg + 1] candidates per scan workgroup, then exclusive offsets
+	uint32_t *ncand;        // [1]
+	uint64_t *cand_pos;     // [max_frames]
+	uint64_t *cand_end;     // [max_frames] byte just past the frame
+	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bits 4..7 assignment (0..3)
+	uint32_t *cand_bs;      // [max_frames]
+	uint64_t *cand_num;     // [max_frames] frame or sample number from the header
+	int32_t  *ws;           // [max_frames][channels][max_bs] subframe outputs before decorrelation
+	uint32_t *frame_of;     // [max_frames] candidate index of the r-th accepted frame
+	uint64_t *sample_off;   // [max_frames] first wide sample of the r-th accepted frame
+	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
+	const uint16_t *crc_tab;   // [256] CRC-16 byte table
+	const uint16_t *crc_segmul;// [64] x^(8 * crc_seg_bytes * j)
+};
+
+// ---- header parsing shared by the scan and the decode kernels
+
+__device__ __forceinline__ uint32_t fd_byte(const uint8_t *b, uint64_t nbytes, uint64_t i) { return i < nbytes ? b[i] : 0u; }
+
+struct FdHeader { uint32_t blocksize, assignment, channels, bps, hdr_bytes; uint64_t number; };
+
+__device__ bool fd_parse_header(const uint8_t *__restrict__ b, uint64_t nbytes, uint64_t pos, const FdCfg &c, FdHeader &h)
+{
+	if(pos + 6 > nbytes) return false;
+	if(b[pos] != 0xffu || (b[pos + 1] & 0xfeu) != 0xf8u) return false;      // sync 11111111 111110, reserved 0 (stream_decoder.c:1967-1985, :2179)
+	const uint32_t b2 = b[pos + 2], b3 = b[pos + 3];
+	const uint32_t bs_code = b2 >> 4, sr_code = b2 & 15u, ch_code = b3 >> 4, bps_code = (b3 >> 1) & 7u;
+	if(b3 & 1u) return false;                                                 // :2329 reserved bit
+	if(bs_code == 0 || sr_code == 15u) return false;                         // :2203, :2283
+	if(ch_code > 10u) return false;                                          // :2296-2327
+	if(bps_code == 3u || bps_code == 7u) return false;                       // :2331-2360
+	uint32_t bps = c.bps;
+	switch(bps_code) { case 1: bps = 8; break; case 2: bps = 12; break; case 4: bps = 16; break; case 5: bps = 20; break; case 6: bps = 24; break; default: break; }
+	if(bps != c.bps) return false;
+	h.bps = bps;
+	if(ch_code < 8u) { h.channels = ch_code + 1u; h.assignment = 0; } else { h.channels = 2; h.assignment = ch_code - 7u; }
+	if(h.channels != c.channels) return false;
+	// UTF-8 coded frame / sample number (bitreader.c FLAC__bitreader_read_utf8_uint64)
+	uint64_t p = pos + 4;
+	const uint32_t first = fd_byte(b, nbytes, p++);
+	uint32_t extra; uint64_t v;
+	if(!(first & 0x80u)) { extra = 0; v = first; }
+	else if((first & 0xE0u) == 0xC0u) { extra = 1; v = first & 0x1Fu; }
+	else if((first & 0xF0u) == 0xE0u) { extra = 2; v = first & 0x0Fu; }
+	else if((first & 0xF8u) == 0xF0u) { extra = 3; v = first & 0x07u; }
+	else if((first & 0xFCu) == 0xF8u) { extra = 4; v = first & 0x03u; }
+	else if((first & 0xFEu) == 0xFCu) { extra = 5; v = first & 0x01u; }
+	else if(first == 0xFEu) { extra = 6; v = 0; }
+	else return false;
+	for(uint32_t i = 0; i < extra; i++) { const uint32_t x = fd_byte(b, nbytes, p++); if((x & 0xC0u) != 0x80u) return false; v = (v << 6) | (x & 0x3Fu); }
+	h.number = v;
+	uint32_t bs;
+	switch(bs_code) {
+	case 1: bs = 192; break; case 2: case 3: case 4: case 5: bs = 576u << (bs_code - 2u); break;
+	case 6: bs = fd_byte(b, nbytes, p++) + 1u; break;
+	case 7: bs = ((fd_byte(b, nbytes, p) << 8) | fd_byte(b, nbytes, p + 1)) + 1u; p += 2; break;
+	default: bs = 256u << (bs_code - 8u); break;
+	}
+	if(bs > c.max_bs) return false;
+	h.blocksize = bs;
+	if(sr_code == 12u) p += 1; else if(sr_code == 13u || sr_code == 14u) p += 2;
+	if(p + 1 > nbytes) return false;
+	// CRC-8 over the header bytes (stream_decoder.c:2416)
+	uint32_t crc = 0;
+	for(uint64_t i = pos; i < p; i++) { crc ^= b[i]; for(int k = 0; k < 8; k++) crc = (crc & 0x80u) ? ((crc << 1) ^ 0x07u) & 0xffu : (crc << 1) & 0xffu; }
+	if(crc != b[p]) return false;
+	h.hdr_bytes = (uint32_t)(p + 1 - pos);
+	return true;
+}
+
+// ---- candidate scan: count, offsets, ordered write
+
+template<bool WRITE>
+__global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict__ b, FdCfg c, FdWork w)
+{
+	__shared__ uint32_t s_wave[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	const uint64_t p0 = (uint64_t)blockIdx.x * FD_SCAN_BYTES + (uint64_t)tid * 16u;
+	uint32_t mask = 0;
+	for(uint32_t k = 0; k < 16; k++) {
+		const uint64_t p = p0 + k;
+		if(p + 1 < c.nbytes && b[p] == 0xffu && (b[p + 1] & 0xfeu) == 0xf8u) { FdHeader h; if(fd_parse_header(b, c.nbytes, p, c, h)) mask |= 1u << k; }
+	}
+	const uint32_t cnt = (uint32_t)__popc(mask);
+	// in-workgroup exclusive scan of the per-thread counts
+	uint32_t inc = cnt;
+#pragma unroll
+	for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
+	if(lane == 63u) s_wave[wv] = inc;
+	__syncthreads();
+	uint32_t pre = 0;
+	for(uint32_t i = 0; i < wv; i++) pre += s_wave[i];
+	if(!WRITE) { if(tid == 255u) w.wg_count[blockIdx.x] = pre + inc; }
+	else {
+		uint32_t at = w.wg_count[blockIdx.x] + pre + inc - cnt;
+		for(uint32_t k = 0; k < 16; k++) if(mask & (1u << k)) { if(at < c.max_frames) w.cand_pos[at] = p0 + k; at++; }
+	}
+}
+
+__global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w)
+{
+	__shared__ uint32_t wave_tot[16];
+	__shared__ uint32_t carry;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	if(tid == 0) carry = 0;
+	__syncthreads();
+	for(uint32_t base = 0; base < c.nscan_wg; base += 1024) {
+		const uint32_t i = base + tid;
+		const uint32_t v = i < c.nscan_wg ? w.wg_count[i] : 0u;
+		uint32_t inc = v;
+#pragma unroll
+		for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
+		if(lane == 63u) wave_tot[wv] = inc;
+		__syncthreads();
+		uint32_t pre = carry;
+		for(uint32_t k = 0; k < wv; k++) pre += wave_tot[k];
+		if(i < c.nscan_wg) w.wg_count[i] = pre + inc - v;
+		__syncthreads();
+		if(tid == 1023u) carry = pre + inc;
+		__syncthreads();
+	}
+	if(tid == 0) { w.ncand[0] = carry; }
+}
+
+// ---- speculative decode, one lane per candidate
+
+struct BitReader {
+	const uint8_t *b; uint64_t nbytes, widx, bitpos; unsigned long long buf; uint32_t avail; bool err;
+	__device__ __forceinline__ uint32_t load_word(uint64_t wi) const
+	{
+		const uint64_t off = wi * 4u;
+		if(off + 4u <= nbytes) return __builtin_bswap32(*(const uint32_t*)(b + off));
+		uint32_t v = 0;
+		for(uint32_t k = 0; k < 4; k++) v = (v << 8) | (off + k < nbytes ? (uint32_t)b[off + k] : 0u);
+		return v;
+	}
+	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)load_word(widx++) << (32u - avail); avail += 32u; } }
+	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos)
+	{
+		b = base; nbytes = nb; widx = pos >> 2; buf = 0; avail = 0; err = false; bitpos = (pos >> 2) * 32u;
+		refill();
+		const uint32_t skip = (uint32_t)(pos & 3u) * 8u;
+		buf <<= skip; avail -= skip; bitpos += skip;
+	}
+	// n in 1..32
+	__device__ __forceinline__ uint32_t read(uint32_t n)
+	{
+		refill();
+		const uint32_t v = (uint32_t)(buf >> (64u - n));
+		buf <<= n; avail -= n; bitpos += n;
+		return v;
+	}
+	__device__ __forceinline__ int32_t read_signed(uint32_t n)
+	{
+		if(n == 0) return 0;
+		const uint32_t v = read(n);
+		return n < 32u ? (int32_t)(v << (32u - n)) >> (32u - n) : (int32_t)v;
+	}
+	// number of zero bits before the next one bit; consumes them and the one
+	__device__ __forceinline__ uint32_t read_unary()
+	{
+		uint32_t q = 0;
+		for(;;) {
+			refill();
+			if(buf == 0) {
+				q += avail; bitpos += avail; avail = 0;
+				if(bitpos > nbytes * 8u + 64u || q > (1u << 26)) { err = true; return 0; }
+				continue;
+			}
+			const uint32_t lz = (uint32_t)__clzll((long long)buf);
+			q += lz;
+			buf <<= (lz + 1u) & 63u; if(lz == 63u) buf = 0;
+			avail -= lz + 1u; bitpos += lz + 1u;
+			return q;
+		}
+	}
+};
+
+#define FD_RING 32u
+
+__global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
+{
+	// per-lane predictor coefficients and sample history, column `lane` of [32][64] arrays:
+	// any mix of per-lane row indices stays bank-conflict free
+	__shared__ int32_t s_q[FD_RING][64];
+	__shared__ int32_t s_h[FD_RING][64];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t ci = blockIdx.x * 64u + lane;
+	const uint32_t ncand = w.ncand[0] < c.max_frames ? w.ncand[0] : c.max_frames;
+	if(ci >= ncand) return;
+	const uint64_t pos = w.cand_pos[ci];
+	FdHeader h;
+	uint32_t info = 0;
+	w.cand_end[ci] = pos; w.cand_bs[ci] = 0; w.cand_num[ci] = 0;
+	if(!fd_parse_header(bytes, c.nbytes, pos, c, h)) { w.cand_info[ci] = 0; return; }
+	const uint32_t n = h.blocksize;
+	BitReader br; br.init(bytes, c.nbytes, pos + h.hdr_bytes);
+	bool ok = true;
+	for(uint32_t ch = 0; ch < h.channels && ok; ch++) {
+		uint32_t bps = h.bps;
+		if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
+		int32_t *out = w.ws + ((size_t)ci * c.channels + ch) * c.max_bs;
+		uint32_t head = br.read(8);
+		if(head & 0x80u) { ok = false; break; }                                           // :2481
+		uint32_t wasted = 0;
+		if(head & 1u) { wasted = br.read_unary() + 1u; if(wasted >= bps) { ok = false; break; } bps -= wasted; }
+		head &= 0xfeu;
+		if(head == 0) { const int32_t v = br.read_signed(bps) << wasted; for(uint32_t i = 0; i < n; i++) out[i] = v; }     // constant :2526
+		else if(head == 2) { for(uint32_t i = 0; i < n; i++) out[i] = br.read_signed(bps) << wasted; }                    // verbatim :2698
+		else if((head >= 16 && head <= 24) || head >= 64) {
+			const bool lpc = head >= 64;
+			const uint32_t order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
+			if(order > n || (!lpc && order > 4u)) { ok = false; break; }
+			int32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0; // fixed predictor history: x[i-1..i-4]
+			uint32_t hp = 0;
+			for(uint32_t i = 0; i < order; i++) {
+				const int32_t v = br.read_signed(bps);
+				out[i] = v << wasted;
+				s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
+				h3 = h2; h2 = h1; h1 = h0; h0 = v;
+			}
+			uint32_t prec = 0, shift = 0, wide = 0;
+			if(lpc) {
+				prec = br.read(4);
+				if(prec == 15u) { ok = false; break; }                                   // :2628
+				prec++;
+				const int32_t sh = br.read_signed(5);
+				if(sh < 0) { ok = false; break; }     // never produced by the reference encoder (lpc.c:225-260); shifting by a negative count is undefined there
+				shift = (uint32_t)sh;
+				for(uint32_t j = 0; j < order; j++) s_q[j][lane] = br.read_signed(prec);
+				wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
+			}
+			const uint32_t method = br.read(2);
+			if(method > 1u) { ok = false; break; }                                       // :2580
+			const uint32_t po = br.read(4), plen = method ? 5u : 4u, esc = method ? 31u : 15u;
+			if(po == 0) { if(n < order) { ok = false; break; } } else if((n >> po) < order) { ok = false; break; } // :2732-2745
+			if(po > 0 && ((n >> po) << po) != n) { ok = false; break; }
+			uint32_t i = order;
+			for(uint32_t part = 0; part < (1u << po) && ok; part++) {
+				uint32_t cnt = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
+				const uint32_t k = br.read(plen);
+				uint32_t raw = 0;
+				const bool escaped = k >= esc;
+				if(escaped) raw = br.read(5);
+				for(; cnt > 0; cnt--, i++) {
+					int32_t r;
+					if(!escaped) {
+						const uint32_t qv = br.read_unary();
+						const uint32_t low = k ? br.read(k) : 0u;
+						const uint32_t u = (qv << k) | low;
+						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+					}
+					else r = br.read_signed(raw);
+					int32_t x;
+					if(lpc) {
+						if(wide) { long long sum = 0; for(uint32_t j = 0; j < order; j++) sum += (long long)s_q[j][lane] * (long long)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift)); }
+						else { uint32_t sum = 0; for(uint32_t j = 0; j < order; j++) sum += (uint32_t)s_q[j][lane] * (uint32_t)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift)); }
+						s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
+					}
+					else {
+						const uint32_t a = (uint32_t)h0, bb = (uint32_t)h1, cc = (uint32_t)h2, d = (uint32_t)h3, rr = (uint32_t)r;
+						const uint32_t v = order == 0 ? rr : order == 1 ? rr + a : order == 2 ? rr + 2u*a - bb : order == 3 ? rr + 3u*a - 3u*bb + cc : rr + 4u*a - 6u*bb + 4u*cc - d;
+						x = (int32_t)v;
+						h3 = h2; h2 = h1; h1 = h0; h0 = x;
+					}
+					out[i] = (int32_t)((uint32_t)x << wasted);
+					if(br.err) { ok = false; break; }
+				}
+			}
+		}
+		else { ok = false; break; }                                                       // reserved subframe types :2494, :2505
+		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
+	}
+	if(ok) {
+		// zero padding to the byte boundary must be zero (:2779-2795), then the 16-bit CRC
+		const uint32_t pad = (uint32_t)((8u - (br.bitpos & 7u)) & 7u);
+		if(pad && br.read(pad) != 0) ok = false;
+		(void)br.read(16);
+		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
+	}
+	if(ok) {
+		info = 1u | (h.assignment << 4);
+		w.cand_end[ci] = br.bitpos >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
+	}
+	w.cand_info[ci] = info;
+}
+
+// CRC-16 over every parsed candidate, one 64-thread workgroup per candidate
+__global__ void __launch_bounds__(64) fd_crc_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
+{
+	__shared__ uint16_t tab[256];
+	const uint32_t ci = blockIdx.x, tid = threadIdx.x;
+	const uint32_t info = w.cand_info[ci];
+	if(!(info & 1u)) return;
+	for(uint32_t i = tid; i < 256; i += 64) tab[i] = w.crc_tab[i];
+	__syncthreads();
+	const uint64_t pos = w.cand_pos[ci], end = w.cand_end[ci];
+	const uint64_t len = end - pos;
+	const uint64_t seg = c.crc_seg_bytes;
+	uint32_t crc = 0;
+	if(len <= seg * 64u) {
+		const uint64_t e1 = (seg * tid < len) ? len - seg * tid : 0u, b0 = (e1 > seg) ? e1 - seg : 0u;
+		if(e1 > 0) {
+			for(uint64_t i = b0; i < e1; i++) crc = ((crc << 8) & 0xffffu) ^ tab[(crc >> 8) ^ bytes[pos + i]];
+			// multiply by x^(8 * seg * tid)
+			uint32_t m = w.crc_segmul[tid], r = 0;
+			for(int i = 15; i >= 0; i--) { r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu; if((m >> i) & 1u) r ^= crc; }
+			crc = r;
+		}
+#pragma unroll
+		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
+	}
+	else crc = 1; // longer than any frame this stream can hold
+	// the CRC of a frame including its own CRC-16 field is zero
+	if(tid == 0 && crc == 0) w.cand_info[ci] = info | 2u;
+}
+
+// Accept CRC-valid candidates, check that they tile the range, number them, prefix-sum samples
+__global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
+{
+	__shared__ unsigned long long wave_a[16], wave_b[16];
+	__shared__ unsigned long long carry_a, carry_b;
+	__shared__ uint32_t s_err;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	const uint32_t ncand_raw = w.ncand[0];
+	const uint32_t ncand = ncand_raw < c.max_frames ? ncand_raw : c.max_frames;
+	if(tid == 0) { carry_a = 0; carry_b = 0; s_err = ncand_raw > c.max_frames ? 4u : 0u; }
+	__syncthreads();
+	for(uint32_t base = 0; base < ncand; base += 1024) {
+		const uint32_t i = base + tid;
+		const bool valid = i < ncand && (w.cand_info[i] & 3u) == 3u;
+		const unsigned long long va = valid ? 1u : 0u, vb = valid ? w.cand_bs[i] : 0u;
+		unsigned long long ia = va, ib = vb;
+#pragma unroll
+		for(int o = 1; o < 64; o <<= 1) {
+			const unsigned long long ta = (unsigned long long)__shfl_up((long long)ia, o, 64), tb = (unsigned long long)__shfl_up((long long)ib, o, 64);
+			if(lane >= (uint32_t)o) { ia += ta; ib += tb; }
+		}
+		if(lane == 63u) { wave_a[wv] = ia; wave_b[wv] = ib; }
+		__syncthreads();
+		unsigned long long pa = carry_a, pb = carry_b;
+		for(uint32_t k = 0; k < wv; k++) { pa += wave_a[k]; pb += wave_b[k]; }
+		if(valid) { const uint32_t r = (uint32_t)(pa + ia - 1u); w.frame_of[r] = i; w.sample_off[r] = pb + ib - vb; }
+		__syncthreads();
+		if(tid == 1023u) { carry_a = pa + ia; carry_b = pb + ib; }
+		__syncthreads();
+	}
+	const uint32_t nframes = (uint32_t)carry_a;
+	__syncthreads();
+	// contiguity: frame r+1 starts where frame r ends
+	for(uint32_t r = tid; r + 1 < nframes; r += 1024) if(w.cand_end[w.frame_of[r]] != w.cand_pos[w.frame_of[r + 1]]) atomicOr(&s_err, 1u);
+	__syncthreads();
+	if(tid == 0) {
+		w.result[0] = nframes; w.result[1] = carry_b;
+		w.result[2] = nframes ? w.cand_num[w.frame_of[0]] : 0;
+		w.result[3] = nframes ? w.cand_end[w.frame_of[nframes - 1]] : 0;
+		uint32_t err = s_err;
+		if(nframes == 0) err |= 2u;
+		if(carry_b > c.pcm_cap) err |= 8u;
+		w.result[4] = err;
+		w.result[5] = nframes ? w.cand_pos[w.frame_of[0]] : 0;
+		w.result[6] = ncand_raw;
+	}
+}
+
+// Undo the inter-channel decorrelation (stream_decoder.c:2073-2108) and write interleaved PCM
+__global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, void *__restrict__ pcm)
+{
+	if(w.result[4] != 0) return;
+	const uint32_t r = blockIdx.x;
+	if(r >= (uint32_t)w.result[0]) return;
+	const uint32_t ci = w.frame_of[r];
+	const uint32_t n = w.cand_bs[ci], assignment = (w.cand_info[ci] >> 4) & 15u;
+	const uint64_t s0 = w.sample_off[r];
+	const int32_t *src = w.ws + (size_t)ci * c.channels * c.max_bs;
+	if(c.channels == 2) {
+		for(uint32_t i = threadIdx.x; i < n; i += 256) {
+			int32_t a = src[i], b = src[c.max_bs + i];
+			if(assignment == 1) b = (int32_t)((uint32_t)a - (uint32_t)b);
+			else if(assignment == 2) a = (int32_t)((uint32_t)a + (uint32_t)b);
+			else if(assignment == 3) {
+				const int32_t side = b; const int32_t mid = (int32_t)((uint32_t)a << 1) | (side & 1);
+				a = (int32_t)((uint32_t)mid + (uint32_t)side) >> 1; b = (int32_t)((uint32_t)mid - (uint32_t)side) >> 1;
+			}
+			if(c.pcm_format == FLACAMD_PCM_S16) ((uint32_t*)pcm)[s0 + i] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+			else ((int2*)pcm)[s0 + i] = make_int2(a, b);
+		}
+	}
+	else {
+		const uint32_t total = n * c.channels;
+		for(uint32_t t = threadIdx.x; t < total; t += 256) {
+			const uint32_t i = t / c.channels, ch = t - i * c.channels;
+			const int32_t v = src[(size_t)ch * c.max_bs + i];
+			if(c.pcm_format == FLACAMD_PCM_S16) ((int16_t*)pcm)[(s0 + i) * c.channels + ch] = (int16_t)v;
+			else ((int32_t*)pcm)[(s0 + i) * c.channels + ch] = v;
+		}
+	}
+}
+
+// ------------------------------------------------------------------ host side
+
+static thread_local char fd_last_error[256] = "";
+extern "C" const char *flacamd_last_error(void);
+
+struct flacamd_decoder {
+	int device;
+	FdCfg cfg; FdWork work;
+	void *arena; size_t arena_bytes;
+	size_t max_bytes;
+	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
+};
+
+#define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
+
+static size_t fd_align(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_t channels, uint32_t bits_per_sample,
+	uint32_t max_blocksize, uint32_t max_frames, size_t max_bytes)
+{
+	if(!out || channels == 0 || channels > FLACAMD_MAX_CHANNELS || bits_per_sample < 4 || bits_per_sample > 24 || max_blocksize < 1 || max_blocksize > 65535 || max_frames == 0 || max_bytes == 0)
+		return FLACAMD_E_INVALID_ARGUMENT;
+	*out = 0;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FLACAMD_E_NO_DEVICE;
+	flacamd_decoder *d = (flacamd_decoder*)calloc(1, sizeof *d);
+	if(!d) return FLACAMD_E_OUT_OF_MEMORY;
+	d->device = device; d->max_bytes = max_bytes;
+	FdCfg &c = d->cfg;
+	c.channels = channels; c.bps = bits_per_sample; c.max_bs = max_blocksize; c.max_frames = max_frames;
+	// longest possible frame: header + per channel (head + verbatim-sized body with one spare bit per sample) + footer
+	const size_t max_frame_bytes = 16 + (size_t)channels * (((size_t)max_blocksize * (bits_per_sample + 2) + 7) / 8 + 64) + 2;
+	c.crc_seg_bytes = (uint32_t)((max_frame_bytes + 63) / 64);
+	FD_TRY(hipSetDevice(device));
+	const size_t nwg = (max_bytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES;
+	size_t off = 0;
+	auto take = [&](size_t bytes) { size_t o = off; off = fd_align(off + bytes); return o; };
+	const size_t o_cnt = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
+		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * max_blocksize * 4),
+		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(1024);
+	d->arena_bytes = off;
+	hipError_t he = hipMalloc(&d->arena, off);
+	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
+	uint8_t *b = (uint8_t*)d->arena;
+	FdWork &w = d->work;
+	w.wg_count = (uint32_t*)(b + o_cnt); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
+	w.cand_info = (uint32_t*)(b + o_info); w.cand_bs = (uint32_t*)(b + o_bs); w.cand_num = (uint64_t*)(b + o_num); w.ws = (int32_t*)(b + o_ws);
+	w.frame_of = (uint32_t*)(b + o_fo); w.sample_off = (uint64_t*)(b + o_so); w.result = (uint64_t*)(b + o_res);
+	uint16_t tab[256 + 64];
+	for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }
+	{ unsigned v = 1; for(unsigned j = 0; j < 64; j++) { tab[256 + j] = (uint16_t)v; for(unsigned z = 0; z < c.crc_seg_bytes; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]; } }
+	he = hipMemcpy(b + o_tab, tab, sizeof tab, hipMemcpyHostToDevice);
+	if(he != hipSuccess) { hipFree(d->arena); free(d); return FLACAMD_E_DEVICE; }
+	w.crc_tab = (const uint16_t*)(b + o_tab); w.crc_segmul = (const uint16_t*)(b + o_tab) + 256;
+	*out = d;
+	return FLACAMD_OK;
+}
+
+extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
+{
+	if(!d) return;
+	(void)hipSetDevice(d->device);
+	if(d->arena) (void)hipFree(d->arena);
+	if(d->d_in_stage) (void)hipFree(d->d_in_stage);
+	if(d->d_pcm_stage) (void)hipFree(d->d_pcm_stage);
+	free(d);
+}
+
+extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, size_t nbytes,
+	void *d_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4], void *stream)
+{
+	if(!d || !d_bytes || !d_pcm || nbytes == 0 || nbytes > d->max_bytes) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && d->cfg.bps > 16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(((uintptr_t)d_bytes & 3u) != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	hipStream_t st = (hipStream_t)stream;
+	FD_TRY(hipSetDevice(d->device));
+	FdCfg c = d->cfg;
+	c.nbytes = nbytes; c.nscan_wg = (uint32_t)((nbytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES); c.pcm_format = (uint32_t)pcm_format; c.pcm_cap = pcm_cap_samples;
+	const uint8_t *bytes = (const uint8_t*)d_bytes;
+	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_scan_offsets_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
+	hipLaunchKernelGGL(fd_scan_kernel<true>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
+	uint32_t ncand = 0;
+	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
+	FD_TRY(hipStreamSynchronize(st));
+	if(ncand == 0) return FLACAMD_E_BAD_STREAM;
+	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
+	hipLaunchKernelGGL(fd_decode_kernel, dim3((ncand + 63u) / 64u), dim3(64), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(64), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
+	hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);
+	FD_TRY(hipGetLastError());
+	uint64_t res[8];
+	FD_TRY(hipMemcpyAsync(res, d->work.result, sizeof res, hipMemcpyDeviceToHost, st));
+	FD_TRY(hipStreamSynchronize(st));
+	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
+	if(res[4] & 8u) return FLACAMD_E_CAPACITY;
+	if(res[4] != 0) return FLACAMD_E_BAD_STREAM;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, size_t nbytes,
+	void *h_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4])
+{
+	if(!d || !h_bytes || !h_pcm || nbytes == 0 || nbytes > d->max_bytes) return FLACAMD_E_INVALID_ARGUMENT;
+	FD_TRY(hipSetDevice(d->device));
+	if(!d->d_in_stage) FD_TRY(hipMalloc(&d->d_in_stage, (d->max_bytes + 15) & ~(size_t)15));
+	const size_t sample_bytes = (pcm_format == FLACAMD_PCM_S16 ? 2u : 4u) * (size_t)d->cfg.channels;
+	const size_t need = (size_t)pcm_cap_samples * sample_bytes;
+	if(d->pcm_stage_bytes < need) {
+		if(d->d_pcm_stage) (void)hipFree(d->d_pcm_stage);
+		d->d_pcm_stage = 0; d->pcm_stage_bytes = 0;
+		FD_TRY(hipMalloc(&d->d_pcm_stage, need));
+		d->pcm_stage_bytes = need;
+	}
+	FD_TRY(hipMemcpy(d->d_in_stage, h_bytes, nbytes, hipMemcpyHostToDevice));
+	uint64_t info[4] = {0, 0, 0, 0};
+	const int rc = flacamd_decode_device(d, d->d_in_stage, nbytes, d->d_pcm_stage, pcm_format, pcm_cap_samples, info, 0);
+	if(h_info) memcpy(h_info, info, sizeof info);
+	if(rc != FLACAMD_OK) return rc;
+	FD_TRY(hipMemcpy(h_pcm, d->d_pcm_stage, (size_t)info[1] * sample_bytes, hipMemcpyDeviceToHost));
+	return FLACAMD_OK;
+}

@@ -444,11 +444,4 @@ extern "C" long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h
 	return (long)bytes;
 }
 
-// ---- temporary: decoder / md5 entry points are implemented in decoder.hip / k_md5.hip
-#ifndef FA_HAVE_DECODER
-extern "C" int flacamd_md5_device(int, const void *, int, uint32_t, uint32_t, const uint64_t *, uint32_t, uint8_t *, void *) { return FLACAMD_E_UNSUPPORTED; }
-extern "C" int flacamd_decoder_create(flacamd_decoder **, int, uint32_t, uint32_t, uint32_t, uint32_t, size_t) { return FLACAMD_E_UNSUPPORTED; }
-extern "C" void flacamd_decoder_destroy(flacamd_decoder *) {}
-extern "C" int flacamd_decode_device(flacamd_decoder *, const void *, size_t, void *, int, uint64_t, uint64_t *, void *) { return FLACAMD_E_UNSUPPORTED; }
-extern "C" int flacamd_decode_host(flacamd_decoder *, const uint8_t *, size_t, void *, int, uint64_t, uint64_t *) { return FLACAMD_E_UNSUPPORTED; }
-#endif
+// ---- md5 entry point is implemented in k_md5.hip

@@ -1,0 +1,99 @@
+// MD5 of the unencoded PCM, one lane per independent stream.
+//
+// Replaces FLAC__MD5Accumulate / format_input_ / FLAC__MD5Final (md5.c:216-420): the
+// channels are interleaved, each sample is written little-endian in (bps+7)/8 bytes, and
+// the standard MD5 is run over that byte stream.  MD5 is a strictly serial chain over a
+// stream (each 64-byte block depends on the previous state), so a stream maps to ONE lane
+// and the batch supplies the parallelism: this entry point is for batches of many clips.
+// A single long stream is hashed on a host thread by the stream encoder shim instead.
+#include "engine_types.h"
+#include <hip/hip_runtime.h>
+
+__constant__ uint32_t md5_k[64] = {
+	0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,
+	0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
+	0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,
+	0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
+	0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,
+	0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
+	0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,
+	0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
+
+__device__ __forceinline__ uint32_t rotl(uint32_t v, uint32_t s) { return (v << s) | (v >> (32u - s)); }
+
+__device__ void md5_block(uint32_t (&h)[4], const uint32_t (&m)[16])
+{
+	uint32_t a = h[0], b = h[1], c = h[2], d = h[3];
+#define STEP(F, G, S, I) { const uint32_t f_ = (F) + a + md5_k[I] + m[G]; a = d; d = c; c = b; b = b + rotl(f_, S); }
+#pragma unroll
+	for(int i = 0; i < 16; i++) { const uint32_t s[4] = {7, 12, 17, 22}; STEP((b & c) | (~b & d), i, s[i & 3], i) }
+#pragma unroll
+	for(int i = 16; i < 32; i++) { const uint32_t s[4] = {5, 9, 14, 20}; STEP((d & b) | (~d & c), (5 * i + 1) & 15, s[i & 3], i) }
+#pragma unroll
+	for(int i = 32; i < 48; i++) { const uint32_t s[4] = {4, 11, 16, 23}; STEP(b ^ c ^ d, (3 * i + 5) & 15, s[i & 3], i) }
+#pragma unroll
+	for(int i = 48; i < 64; i++) { const uint32_t s[4] = {6, 10, 15, 21}; STEP(c ^ (b | ~d), (7 * i) & 15, s[i & 3], i) }
+#undef STEP
+	h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+}
+
+__global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
+	const uint64_t *__restrict__ offsets, uint32_t nstreams, uint8_t *__restrict__ digests)
+{
+	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
+	if(sidx >= nstreams) return;
+	const uint64_t s0 = offsets[sidx], s1 = offsets[sidx + 1];
+	const uint32_t nb = (bps + 7u) / 8u;
+	uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+	uint32_t m[16];
+#pragma unroll
+	for(int i = 0; i < 16; i++) m[i] = 0;
+	uint32_t fill = 0;            // bytes in the current block
+	uint64_t total = 0;
+	auto push = [&](uint32_t byte) {
+		// static register indexing: the word index is resolved by a switch the compiler turns into selects
+		const uint32_t wi = fill >> 2, sh = (fill & 3u) * 8u;
+#pragma unroll
+		for(int i = 0; i < 16; i++) if((uint32_t)i == wi) m[i] |= byte << sh;
+		fill++; total++;
+		if(fill == 64u) {
+			md5_block(h, m);
+#pragma unroll
+			for(int i = 0; i < 16; i++) m[i] = 0;
+			fill = 0;
+		}
+	};
+	for(uint64_t i = s0; i < s1; i++)
+		for(uint32_t ch = 0; ch < channels; ch++) {
+			const uint32_t v = (uint32_t)fa_pcm(pcm, fmt, channels, i, ch);
+			for(uint32_t k = 0; k < nb; k++) push((v >> (8u * k)) & 0xffu);
+		}
+	const uint64_t bits = total * 8u;
+	push(0x80u);
+	while(fill != 56u) push(0u);
+	for(uint32_t k = 0; k < 8; k++) push((uint32_t)(bits >> (8u * k)) & 0xffu);
+	for(uint32_t i = 0; i < 16; i++) digests[(size_t)sidx * 16u + i] = (uint8_t)(h[i >> 2] >> (8u * (i & 3u)));
+}
+
+extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
+	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests, void *stream)
+{
+	if(!d_pcm || !h_offsets || !h_digests || nstreams == 0 || channels == 0 || channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FLACAMD_E_NO_DEVICE;
+	hipStream_t st = (hipStream_t)stream;
+	if(hipSetDevice(device) != hipSuccess) return FLACAMD_E_DEVICE;
+	uint64_t *d_off = 0; uint8_t *d_dig = 0;
+	if(hipMalloc((void**)&d_off, (size_t)(nstreams + 1) * 8) != hipSuccess) return FLACAMD_E_OUT_OF_MEMORY;
+	if(hipMalloc((void**)&d_dig, (size_t)nstreams * 16) != hipSuccess) { (void)hipFree(d_off); return FLACAMD_E_OUT_OF_MEMORY; }
+	int rc = FLACAMD_OK;
+	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
+	if(rc == FLACAMD_OK) {
+		hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, nstreams, d_dig);
+		if(hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
+		if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
+	}
+	(void)hipFree(d_off); (void)hipFree(d_dig);
+	return rc;
+}

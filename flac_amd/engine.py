@@ -197,3 +197,48 @@ class Encoder:
 
 def device_count():
     return int(lib().flacamd_device_count())
+
+
+class Decoder:
+    """Frame-parallel decoder for streams of known channels / bits per sample (flacamd_decoder)."""
+
+    def __init__(self, channels, bits_per_sample, max_blocksize, max_frames, max_bytes, device=0):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        _check(self._lib.flacamd_decoder_create(C.byref(self._h), device, channels, bits_per_sample, max_blocksize, max_frames, max_bytes),
+               "flacamd_decoder_create")
+        self.channels, self.bps = channels, bits_per_sample
+
+    def close(self):
+        if self._h:
+            self._lib.flacamd_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_host(self, data, cap_samples, dtype=np.int32):
+        """data: bytes of whole frames. Returns (pcm (samples, channels), info dict)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        fmt = PCM_S16 if np.dtype(dtype) == np.int16 else PCM_S32
+        pcm = np.zeros((cap_samples, self.channels), dtype=dtype)
+        info = (C.c_uint64 * 4)()
+        _check(self._lib.flacamd_decode_host(self._h, buf.ctypes.data, len(buf), pcm.ctypes.data, fmt, cap_samples, info), "flacamd_decode_host")
+        return pcm[:int(info[1])], dict(frames=int(info[0]), samples=int(info[1]), first_number=int(info[2]), bytes=int(info[3]))
+
+    def decode_device(self, d_bytes_ptr, nbytes, d_pcm_ptr, fmt, cap_samples, stream=None):
+        info = (C.c_uint64 * 4)()
+        _check(self._lib.flacamd_decode_device(self._h, d_bytes_ptr, nbytes, d_pcm_ptr, fmt, cap_samples, info, stream), "flacamd_decode_device")
+        return dict(frames=int(info[0]), samples=int(info[1]), first_number=int(info[2]), bytes=int(info[3]))
+
+
+def md5_device(d_pcm_ptr, fmt, channels, bits_per_sample, offsets, device=0, stream=None):
+    """MD5 digests of streams held back to back in device memory; offsets = wide-sample offsets (len n+1)."""
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(off) - 1
+    out = np.zeros((n, 16), dtype=np.uint8)
+    _check(lib().flacamd_md5_device(device, d_pcm_ptr, fmt, channels, bits_per_sample, off.ctypes.data, n, out.ctypes.data, stream), "flacamd_md5_device")
+    return [bytes(r) for r in out]
