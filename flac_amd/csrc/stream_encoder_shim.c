@@ -1,0 +1,490 @@
+/* Host side of the libFLAC-style encoder object (include/flac_amd_stream.h) in plain C.
+ *
+ * Keeps the reference's layer-3 semantics - settings only before init, the init checks
+ * and their status codes, the "fLaC" / STREAMINFO / VORBIS_COMMENT stream head, callbacks
+ * in stream order, min/max frame size, MD5, STREAMINFO back-patching at finish - and hands
+ * the layer-2/1 work (process_frame_ and below) to the HIP engine in batches of frames.
+ * Citations are to /root/reference/src/libFLAC/stream_encoder.c unless noted.
+ */
+#define _FILE_OFFSET_BITS 64
+#include "../../include/flac_amd_stream.h"
+#include "../../include/flac_amd_engine.h"
+#include <stdlib.h>
+#include <string.h>
+#include <sys/types.h>
+
+#define VENDOR_STRING "reference libFLAC 1.2.1 20070917" /* format.c:56-63: decoders and tools compare it */
+
+const char * const FLAC__StreamEncoderStateString[] = { /* :458-468 */
+	"FLAC__STREAM_ENCODER_OK", "FLAC__STREAM_ENCODER_UNINITIALIZED", "FLAC__STREAM_ENCODER_OGG_ERROR",
+	"FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR", "FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA",
+	"FLAC__STREAM_ENCODER_CLIENT_ERROR", "FLAC__STREAM_ENCODER_IO_ERROR", "FLAC__STREAM_ENCODER_FRAMING_ERROR",
+	"FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR" };
+const char * const FLAC__StreamEncoderInitStatusString[] = { /* :470-485 */
+	"FLAC__STREAM_ENCODER_INIT_STATUS_OK", "FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE",
+	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA", "FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED" };
+
+/* ---- MD5 (md5.c), fed with the PCM bytes as format_input_ lays them out (md5.c:273-389) */
+typedef struct { uint32_t h[4]; uint64_t nbytes; uint8_t buf[64]; } md5_state;
+static const uint32_t md5_k[64] = {
+	0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
+	0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
+	0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
+	0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
+static const uint8_t md5_s[64] = { 7,12,17,22,7,12,17,22,7,12,17,22,7,12,17,22, 5,9,14,20,5,9,14,20,5,9,14,20,5,9,14,20, 4,11,16,23,4,11,16,23,4,11,16,23,4,11,16,23, 6,10,15,21,6,10,15,21,6,10,15,21,6,10,15,21 };
+static void md5_block(md5_state *m, const uint8_t *p)
+{
+	uint32_t w[16], a = m->h[0], b = m->h[1], c = m->h[2], d = m->h[3]; int i;
+	for(i = 0; i < 16; i++) w[i] = (uint32_t)p[4*i] | (uint32_t)p[4*i+1] << 8 | (uint32_t)p[4*i+2] << 16 | (uint32_t)p[4*i+3] << 24;
+	for(i = 0; i < 64; i++) {
+		uint32_t f, t; int g;
+		if(i < 16) { f = (b & c) | (~b & d); g = i; }
+		else if(i < 32) { f = (d & b) | (~d & c); g = (5*i + 1) & 15; }
+		else if(i < 48) { f = b ^ c ^ d; g = (3*i + 5) & 15; }
+		else { f = c ^ (b | ~d); g = (7*i) & 15; }
+		t = d; d = c; c = b;
+		f += a + md5_k[i] + w[g];
+		b += (f << md5_s[i]) | (f >> (32 - md5_s[i]));
+		a = t;
+	}
+	m->h[0] += a; m->h[1] += b; m->h[2] += c; m->h[3] += d;
+}
+static void md5_init(md5_state *m) { m->h[0] = 0x67452301; m->h[1] = 0xefcdab89; m->h[2] = 0x98badcfe; m->h[3] = 0x10325476; m->nbytes = 0; }
+static void md5_update(md5_state *m, const uint8_t *p, size_t n)
+{
+	size_t fill = (size_t)(m->nbytes & 63);
+	m->nbytes += n;
+	if(fill) { size_t t = 64 - fill; if(t > n) t = n; memcpy(m->buf + fill, p, t); p += t; n -= t; if(fill + t < 64) return; md5_block(m, m->buf); }
+	while(n >= 64) { md5_block(m, p); p += 64; n -= 64; }
+	if(n) memcpy(m->buf, p, n);
+}
+static void md5_final(md5_state *m, uint8_t out[16])
+{
+	const uint64_t bits = m->nbytes * 8; uint8_t pad[72]; const size_t fill = (size_t)(m->nbytes & 63), n = (fill < 56 ? 56 - fill : 120 - fill); int i;
+	memset(pad, 0, sizeof pad); pad[0] = 0x80;
+	for(i = 0; i < 8; i++) pad[n + i] = (uint8_t)(bits >> (8*i));
+	md5_update(m, pad, n + 8);
+	for(i = 0; i < 16; i++) out[i] = (uint8_t)(m->h[i >> 2] >> (8 * (i & 3)));
+}
+
+/* ---- the object */
+struct FLAC__StreamEncoder {
+	FLAC__StreamEncoderState state;
+	flacamd_params p;                 /* the protected_ settings (include/protected/stream_encoder.h:78-108) */
+	FLAC__bool verify, streamable_subset, do_md5, do_escape_coding;
+	unsigned rice_parameter_search_dist;
+	FLAC__uint64 total_samples_estimate;
+	int device; unsigned batch_frames;
+	/* callbacks */
+	FLAC__StreamEncoderWriteCallback write_cb; FLAC__StreamEncoderSeekCallback seek_cb; FLAC__StreamEncoderTellCallback tell_cb;
+	FLAC__StreamEncoderMetadataCallback metadata_cb; FLAC__StreamEncoderProgressCallback progress_cb; void *client_data;
+	FILE *file;
+	/* stream bookkeeping (:2423-2426, :2505-2511) */
+	FLAC__StreamMetadata streaminfo;
+	FLAC__uint64 streaminfo_offset, audio_offset, bytes_written, samples_written;
+	unsigned frames_written, total_frames_estimate, current_frame_number;
+	md5_state md5;
+	/* engine + batch queue */
+	flacamd_encoder *engine;
+	int32_t *queue; size_t queue_cap_samples, queued;   /* interleaved wide samples */
+	uint8_t *out; size_t out_cap; uint32_t *frame_bytes;
+	uint32_t last_assignment;
+	uint8_t *md5_scratch;
+};
+
+static void set_defaults(FLAC__StreamEncoder *e) /* set_defaults_, :2107-2160 */
+{
+	const int device = e->device; const unsigned batch = e->batch_frames;
+	memset(e, 0, sizeof *e);
+	e->device = device; e->batch_frames = batch ? batch : 1024u;
+	e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
+	e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1;
+	e->p.channels = 2; e->p.bits_per_sample = 16; e->p.sample_rate = 44100; e->p.blocksize = 0;
+	flacamd_params_preset(&e->p, 5);
+}
+
+FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
+{
+	FLAC__StreamEncoder *e = (FLAC__StreamEncoder*)calloc(1, sizeof *e);
+	if(e) set_defaults(e);
+	return e;
+}
+
+static void free_buffers(FLAC__StreamEncoder *e)
+{
+	if(e->engine) { flacamd_encoder_destroy(e->engine); e->engine = 0; }
+	free(e->queue); e->queue = 0; free(e->out); e->out = 0; free(e->frame_bytes); e->frame_bytes = 0; free(e->md5_scratch); e->md5_scratch = 0;
+}
+
+void FLAC__stream_encoder_delete(FLAC__StreamEncoder *e)
+{
+	if(!e) return;
+	/* :601-638: delete finishes without emitting the pending block */
+	if(e->file && e->file != stdout) fclose(e->file);
+	free_buffers(e);
+	free(e);
+}
+
+#define SETTER(name, type, stmt) FLAC__bool FLAC__stream_encoder_##name(FLAC__StreamEncoder *e, type value) { if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0; stmt; return 1; }
+SETTER(set_streamable_subset, FLAC__bool, e->streamable_subset = value)
+SETTER(set_channels, unsigned, e->p.channels = value)
+SETTER(set_bits_per_sample, unsigned, e->p.bits_per_sample = value)
+SETTER(set_sample_rate, unsigned, e->p.sample_rate = value)
+SETTER(set_blocksize, unsigned, e->p.blocksize = value)
+SETTER(set_do_mid_side_stereo, FLAC__bool, e->p.do_mid_side = value ? 1u : 0u)
+SETTER(set_loose_mid_side_stereo, FLAC__bool, e->p.loose_mid_side = value ? 1u : 0u)
+SETTER(set_max_lpc_order, unsigned, e->p.max_lpc_order = value)
+SETTER(set_qlp_coeff_precision, unsigned, e->p.qlp_coeff_precision = value)
+SETTER(set_do_qlp_coeff_prec_search, FLAC__bool, e->p.do_qlp_coeff_prec_search = value ? 1u : 0u)
+SETTER(set_do_exhaustive_model_search, FLAC__bool, e->p.do_exhaustive_model_search = value ? 1u : 0u)
+SETTER(set_min_residual_partition_order, unsigned, e->p.min_residual_partition_order = value)
+SETTER(set_max_residual_partition_order, unsigned, e->p.max_residual_partition_order = value)
+SETTER(set_total_samples_estimate, FLAC__uint64, e->total_samples_estimate = value)
+SETTER(disable_constant_subframes, FLAC__bool, e->p.disable_constant = value ? 1u : 0u)
+SETTER(disable_fixed_subframes, FLAC__bool, e->p.disable_fixed = value ? 1u : 0u)
+SETTER(disable_verbatim_subframes, FLAC__bool, e->p.disable_verbatim = value ? 1u : 0u)
+SETTER(set_do_md5, FLAC__bool, e->do_md5 = value)
+/* :1635-1649 and :1684-1698: stored but never acted on ("not ready yet") */
+SETTER(set_do_escape_coding, FLAC__bool, (void)value; e->do_escape_coding = 0)
+SETTER(set_rice_parameter_search_dist, unsigned, (void)value; e->rice_parameter_search_dist = 0)
+
+FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *e, FLAC__bool value)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	if(value) return 0; /* verify mode is not provided: refuse rather than pretend */
+	e->verify = 0;
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *e, unsigned value) /* :1455-1495 */
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	flacamd_params_preset(&e->p, value > 8 ? 8 : value);
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__StreamMetadata **metadata, unsigned num_blocks)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	return (metadata == 0 && num_blocks == 0) ? 1 : 0;
+}
+
+FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *e, int device)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || device < 0) return 0;
+	e->device = device; return 1;
+}
+FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *e, unsigned frames)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || frames == 0) return 0;
+	e->batch_frames = frames; return 1;
+}
+
+/* :1531-1600: ';'-separated window names, tukey(p) / gauss(stddev) take a parameter,
+ * unknown names are skipped, an empty result falls back to tukey(0.5) */
+FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *e, const char *spec)
+{
+	static const struct { const char *name; uint32_t type; } plain[] = {
+		{"bartlett", FLACAMD_WIN_BARTLETT}, {"bartlett_hann", FLACAMD_WIN_BARTLETT_HANN}, {"blackman", FLACAMD_WIN_BLACKMAN},
+		{"blackman_harris_4term_92db", FLACAMD_WIN_BLACKMAN_HARRIS_4TERM}, {"connes", FLACAMD_WIN_CONNES}, {"flattop", FLACAMD_WIN_FLATTOP},
+		{"hamming", FLACAMD_WIN_HAMMING}, {"hann", FLACAMD_WIN_HANN}, {"kaiser_bessel", FLACAMD_WIN_KAISER_BESSEL}, {"nuttall", FLACAMD_WIN_NUTTALL},
+		{"rectangle", FLACAMD_WIN_RECTANGLE}, {"triangle", FLACAMD_WIN_TRIANGLE}, {"welch", FLACAMD_WIN_WELCH} };
+	if(!e || !spec || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	e->p.num_apodizations = 0;
+	for(;;) {
+		const char *sep = strchr(spec, ';');
+		const size_t n = sep ? (size_t)(sep - spec) : strlen(spec);
+		size_t i; int matched = 0;
+		for(i = 0; i < sizeof plain / sizeof plain[0] && !matched; i++)
+			if(n == strlen(plain[i].name) && 0 == strncmp(plain[i].name, spec, n)) { e->p.apod_type[e->p.num_apodizations++] = plain[i].type; matched = 1; }
+		if(!matched && n > 7 && 0 == strncmp("gauss(", spec, 6)) {
+			const float sd = (float)strtod(spec + 6, 0);
+			if(sd > 0.0 && sd <= 0.5) { e->p.apod_param[e->p.num_apodizations] = sd; e->p.apod_type[e->p.num_apodizations++] = FLACAMD_WIN_GAUSS; }
+		}
+		else if(!matched && n > 7 && 0 == strncmp("tukey(", spec, 6)) {
+			const float pp = (float)strtod(spec + 6, 0);
+			if(pp >= 0.0 && pp <= 1.0) { e->p.apod_param[e->p.num_apodizations] = pp; e->p.apod_type[e->p.num_apodizations++] = FLACAMD_WIN_TUKEY; }
+		}
+		if(e->p.num_apodizations == 32) break;
+		if(sep) spec = sep + 1; else break;
+	}
+	if(e->p.num_apodizations == 0) { e->p.num_apodizations = 1; e->p.apod_type[0] = FLACAMD_WIN_TUKEY; e->p.apod_param[0] = 0.5f; }
+	return 1;
+}
+
+#define GETTER(name, type, expr) type FLAC__stream_encoder_##name(const FLAC__StreamEncoder *e) { return expr; }
+GETTER(get_state, FLAC__StreamEncoderState, e->state)
+GETTER(get_verify, FLAC__bool, e->verify)
+GETTER(get_streamable_subset, FLAC__bool, e->streamable_subset)
+GETTER(get_channels, unsigned, e->p.channels)
+GETTER(get_bits_per_sample, unsigned, e->p.bits_per_sample)
+GETTER(get_sample_rate, unsigned, e->p.sample_rate)
+GETTER(get_blocksize, unsigned, e->p.blocksize)
+GETTER(get_do_mid_side_stereo, FLAC__bool, (FLAC__bool)e->p.do_mid_side)
+GETTER(get_loose_mid_side_stereo, FLAC__bool, (FLAC__bool)e->p.loose_mid_side)
+GETTER(get_max_lpc_order, unsigned, e->p.max_lpc_order)
+GETTER(get_qlp_coeff_precision, unsigned, e->p.qlp_coeff_precision)
+GETTER(get_do_qlp_coeff_prec_search, FLAC__bool, (FLAC__bool)e->p.do_qlp_coeff_prec_search)
+GETTER(get_do_escape_coding, FLAC__bool, e->do_escape_coding)
+GETTER(get_do_exhaustive_model_search, FLAC__bool, (FLAC__bool)e->p.do_exhaustive_model_search)
+GETTER(get_min_residual_partition_order, unsigned, e->p.min_residual_partition_order)
+GETTER(get_max_residual_partition_order, unsigned, e->p.max_residual_partition_order)
+GETTER(get_rice_parameter_search_dist, unsigned, e->rice_parameter_search_dist)
+GETTER(get_total_samples_estimate, FLAC__uint64, e->total_samples_estimate)
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[e->state]; }
+
+/* ---- writing: write_frame_ (:2431-2518) and write_bitbuffer_'s frame size tracking (:2423-2426) */
+static FLAC__bool emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, unsigned samples)
+{
+	FLAC__uint64 pos = 0;
+	if(e->tell_cb && e->tell_cb(e, &pos, e->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+	if(samples == 0 && (buf[0] & 0x7f) == 0 && bytes == 38) e->streaminfo_offset = pos; /* the STREAMINFO block going by */
+	if(e->write_cb(e, buf, bytes, samples, e->current_frame_number, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
+	e->bytes_written += bytes; e->samples_written += samples;
+	if(e->frames_written < e->current_frame_number + 1) e->frames_written = e->current_frame_number + 1;
+	if(samples > 0) {
+		FLAC__StreamMetadata_StreamInfo *si = &e->streaminfo.data.stream_info;
+		if(bytes < si->min_framesize) si->min_framesize = (unsigned)bytes;
+		if(bytes > si->max_framesize) si->max_framesize = (unsigned)bytes;
+	}
+	return 1;
+}
+
+/* file callbacks (:4262-4337) */
+static FLAC__StreamEncoderSeekStatus file_seek(const FLAC__StreamEncoder *e, FLAC__uint64 off, void *cd) { (void)cd; return fseeko(e->file, (off_t)off, SEEK_SET) < 0 ? FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR : FLAC__STREAM_ENCODER_SEEK_STATUS_OK; }
+static FLAC__StreamEncoderTellStatus file_tell(const FLAC__StreamEncoder *e, FLAC__uint64 *off, void *cd)
+{
+	const off_t o = ftello(e->file); (void)cd;
+	if(o < 0) return FLAC__STREAM_ENCODER_TELL_STATUS_ERROR;
+	*off = (FLAC__uint64)o; return FLAC__STREAM_ENCODER_TELL_STATUS_OK;
+}
+static FLAC__StreamEncoderWriteStatus file_write(const FLAC__StreamEncoder *e, const FLAC__byte buf[], size_t bytes, unsigned samples, unsigned frame, void *cd)
+{
+	(void)cd; (void)frame;
+	if(fwrite(buf, 1, bytes, e->file) != bytes) return FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR;
+	if(e->progress_cb && samples > 0) /* the counters are updated after this callback returns, hence the +bytes etc. (:4324-4331) */
+		e->progress_cb(e, e->bytes_written + bytes, e->samples_written + samples, e->frames_written + 1, e->total_frames_estimate, e->client_data);
+	return FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
+}
+
+static void put_be(uint8_t *p, uint64_t v, unsigned nbytes) { unsigned i; for(i = 0; i < nbytes; i++) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
+
+static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
+	FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
+{
+	flacamd_params *p = &e->p;
+	int rc;
+	/* the checks and their order are init_stream_internal_'s (:656-766) */
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!wcb || (scb && !tcb)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS;
+	if(p->channels == 0 || p->channels > 8) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS;
+	if(p->channels != 2) { p->do_mid_side = 0; p->loose_mid_side = 0; } else if(!p->do_mid_side) p->loose_mid_side = 0;
+	if(p->bits_per_sample < 4 || p->bits_per_sample > 24) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE;
+	if(p->sample_rate == 0 || p->sample_rate > 655350) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE;
+	if(p->blocksize == 0) p->blocksize = p->max_lpc_order == 0 ? 1152 : 4096;
+	if(p->blocksize < 16 || p->blocksize > 65535) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE;
+	if(p->max_lpc_order > 32) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER;
+	if(p->blocksize < p->max_lpc_order) return FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER;
+	if(p->qlp_coeff_precision != 0 && (p->qlp_coeff_precision < 5 || p->qlp_coeff_precision > 15)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION;
+	if(e->streamable_subset) { /* :737-761 with format.c's subset predicates */
+		const unsigned bs = p->blocksize, sr = p->sample_rate, b = p->bits_per_sample;
+		if(bs > 16384 || (sr <= 48000 && bs > 4608)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+		if(sr >= (1u << 16) && !(sr % 1000 == 0 || sr % 10 == 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+		if(b != 8 && b != 12 && b != 16 && b != 20 && b != 24) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+		if(p->max_residual_partition_order > 8) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+		if(sr <= 48000 && (bs > 4608 || p->max_lpc_order > 12)) return FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE;
+	}
+	rc = flacamd_params_resolve(p); /* fills the automatic precision, clips the partition orders */
+	if(rc != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; } /* legal for the reference, outside the engine's limits */
+
+	e->state = FLAC__STREAM_ENCODER_OK;
+	e->write_cb = wcb; e->seek_cb = scb; e->tell_cb = tcb; e->metadata_cb = mcb; e->client_data = client_data;
+	e->current_frame_number = 0; e->queued = 0; e->last_assignment = 0;
+	e->streaminfo_offset = 0; e->audio_offset = 0;
+
+	rc = flacamd_encoder_create(&e->engine, e->device, p, e->batch_frames);
+	if(rc != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	e->queue_cap_samples = (size_t)e->batch_frames * p->blocksize + p->blocksize; /* one spare block: a batch goes out only once a later sample is known */
+	e->queue = (int32_t*)malloc(sizeof(int32_t) * e->queue_cap_samples * p->channels);
+	e->out_cap = flacamd_encoder_max_output_bytes(e->engine, e->batch_frames);
+	e->out = (uint8_t*)malloc(e->out_cap);
+	e->frame_bytes = (uint32_t*)malloc(sizeof(uint32_t) * e->batch_frames);
+	e->md5_scratch = (uint8_t*)malloc((size_t)65536 * 4);
+	if(!e->queue || !e->out || !e->frame_bytes || !e->md5_scratch) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+
+	/* stream head: "fLaC", STREAMINFO, empty VORBIS_COMMENT carrying the vendor string (:1034-1106,
+	 * layouts stream_encoder_framing.c:50-110, :134-160) */
+	{
+		static const uint8_t magic[4] = { 'f', 'L', 'a', 'C' };
+		uint8_t b[64]; FLAC__StreamMetadata_StreamInfo *si = &e->streaminfo.data.stream_info;
+		const size_t vlen = strlen(VENDOR_STRING);
+		if(!emit(e, magic, 4, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		e->streaminfo.type = 0; e->streaminfo.is_last = 0; e->streaminfo.length = 34;
+		si->min_blocksize = si->max_blocksize = p->blocksize; si->min_framesize = si->max_framesize = 0;
+		si->sample_rate = p->sample_rate; si->channels = p->channels; si->bits_per_sample = p->bits_per_sample;
+		si->total_samples = e->total_samples_estimate; memset(si->md5sum, 0, 16);
+		if(e->do_md5) md5_init(&e->md5);
+		b[0] = 0; put_be(b + 1, 34, 3);
+		put_be(b + 4, si->min_blocksize, 2); put_be(b + 6, si->max_blocksize, 2); put_be(b + 8, 0, 3); put_be(b + 11, 0, 3);
+		put_be(b + 14, ((uint64_t)si->sample_rate << 44) | ((uint64_t)(si->channels - 1) << 41) | ((uint64_t)(si->bits_per_sample - 1) << 36) | (si->total_samples & 0xFFFFFFFFFull), 8);
+		memset(b + 22, 0, 16);
+		if(!emit(e, b, 38, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		si->min_framesize = (1u << 24) - 1; si->total_samples = 0; /* :1075-1077 */
+		b[0] = 0x80 | 4; put_be(b + 1, 8 + vlen, 3);
+		b[4] = (uint8_t)vlen; b[5] = b[6] = b[7] = 0; memcpy(b + 8, VENDOR_STRING, vlen); memset(b + 8 + vlen, 0, 4);
+		if(!emit(e, b, 4 + 8 + vlen, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
+	if(e->tell_cb && e->tell_cb(e, &e->audio_offset, e->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
+	FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
+{
+	return init_internal(e, wcb, scb, tcb, mcb, client_data);
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *client_data)
+{
+	FLAC__StreamEncoderInitStatus st;
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!file) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	e->file = file; e->progress_cb = pcb; e->bytes_written = 0; e->samples_written = 0; e->frames_written = 0;
+	st = init_internal(e, file_write, file == stdout ? 0 : file_seek, file == stdout ? 0 : file_tell, 0, client_data);
+	if(st != FLAC__STREAM_ENCODER_INIT_STATUS_OK) return st;
+	e->total_frames_estimate = (unsigned)((e->total_samples_estimate + e->p.blocksize - 1) / e->p.blocksize);
+	return st;
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *e, const char *filename, FLAC__StreamEncoderProgressCallback pcb, void *client_data)
+{
+	FILE *f;
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	f = filename ? fopen(filename, "w+b") : stdout; /* :1290-1308 */
+	if(!f) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	return FLAC__stream_encoder_init_FILE(e, f, pcb, client_data);
+}
+
+/* Code `nsamples` queued wide samples on the engine and replay the per-frame writes. */
+static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final_block)
+{
+	uint64_t total = 0; uint32_t last = 0; size_t off = 0; unsigned f;
+	const unsigned N = e->p.blocksize, nframes = (unsigned)((nsamples + N - 1) / N);
+	const int rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
+		e->out, e->out_cap, e->frame_bytes, &total, &last);
+	if(rc != FLACAMD_OK) { e->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR; return 0; }
+	e->last_assignment = last;
+	for(f = 0; f < nframes; f++) {
+		const unsigned samples = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
+		if(!emit(e, e->out + off, e->frame_bytes[f], samples)) return 0;
+		off += e->frame_bytes[f];
+		e->current_frame_number++;
+		e->streaminfo.data.stream_info.total_samples += samples; /* :2920 */
+	}
+	return 1;
+}
+
+static void md5_feed(FLAC__StreamEncoder *e, const int32_t *interleaved, size_t nvalues)
+{
+	const unsigned nb = (e->p.bits_per_sample + 7) / 8; size_t i, fill = 0; uint8_t *t = e->md5_scratch; unsigned b;
+	for(i = 0; i < nvalues; i++) {
+		const uint32_t v = (uint32_t)interleaved[i];
+		for(b = 0; b < nb; b++) t[fill++] = (uint8_t)(v >> (8 * b));
+		if(fill + 4 > (size_t)65536 * 4) { md5_update(&e->md5, t, fill); fill = 0; }
+	}
+	if(fill) md5_update(&e->md5, t, fill);
+}
+
+/* queue `n` wide samples already interleaved at the queue tail, then flush whole batches.
+ * The reference codes a block once blocksize+1 samples are known (:2006, :2062), so a batch
+ * only goes out when at least one later sample has arrived. */
+static FLAC__bool after_append(FLAC__StreamEncoder *e)
+{
+	const size_t batch = (size_t)e->batch_frames * e->p.blocksize;
+	while(e->queued > batch) {
+		const size_t rest = e->queued - batch;
+		if(!flush_batch(e, batch, 0)) return 0;
+		memmove(e->queue, e->queue + batch * e->p.channels, sizeof(int32_t) * rest * e->p.channels);
+		e->queued = rest;
+	}
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, const FLAC__int32 buffer[], unsigned samples)
+{
+	size_t done = 0;
+	if(!e || e->state != FLAC__STREAM_ENCODER_OK) return 0;
+	if(e->do_md5) md5_feed(e, buffer, (size_t)samples * e->p.channels);
+	while(done < samples) {
+		size_t n = e->queue_cap_samples - e->queued;
+		if(n > samples - done) n = samples - done;
+		memcpy(e->queue + e->queued * e->p.channels, buffer + done * e->p.channels, sizeof(int32_t) * n * e->p.channels);
+		e->queued += n; done += n;
+		if(!after_append(e)) return 0;
+	}
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int32 * const buffer[], unsigned samples)
+{
+	size_t done = 0; const unsigned ch = e ? e->p.channels : 0;
+	if(!e || e->state != FLAC__STREAM_ENCODER_OK) return 0;
+	while(done < samples) {
+		size_t n = e->queue_cap_samples - e->queued, i; unsigned c;
+		int32_t *dst = e->queue + e->queued * ch;
+		if(n > samples - done) n = samples - done;
+		for(i = 0; i < n; i++) for(c = 0; c < ch; c++) dst[i * ch + c] = buffer[c][done + i];
+		if(e->do_md5) md5_feed(e, dst, n * ch);
+		e->queued += n; done += n;
+		if(!after_append(e)) return 0;
+	}
+	return 1;
+}
+
+FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e) /* :1310-1377 */
+{
+	FLAC__bool error = 0;
+	if(!e) return 0;
+	if(e->state == FLAC__STREAM_ENCODER_UNINITIALIZED) return 1;
+	if(e->state == FLAC__STREAM_ENCODER_OK && e->queued > 0) { if(!flush_batch(e, e->queued, 1)) error = 1; e->queued = 0; }
+	if(e->do_md5) md5_final(&e->md5, e->streaminfo.data.stream_info.md5sum);
+	if(e->state == FLAC__STREAM_ENCODER_OK) {
+		if(e->seek_cb) { /* update_metadata_ (:2521-2620): MD5, total samples, min/max frame size patched in place */
+			const FLAC__StreamMetadata_StreamInfo *si = &e->streaminfo.data.stream_info;
+			uint8_t b[6]; int ok = 1;
+			FLAC__StreamEncoderSeekStatus ss;
+			e->current_frame_number = 0;
+			if((ss = e->seek_cb(e, e->streaminfo_offset + 22, e->client_data)) == FLAC__STREAM_ENCODER_SEEK_STATUS_OK) {
+				if(e->write_cb(e, si->md5sum, 16, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+			} else { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+			if(ok) {
+				b[0] = (uint8_t)(((si->bits_per_sample - 1) << 4) | ((si->total_samples >> 32) & 0x0F)); put_be(b + 1, si->total_samples & 0xFFFFFFFFu, 4);
+				if((ss = e->seek_cb(e, e->streaminfo_offset + 17, e->client_data)) == FLAC__STREAM_ENCODER_SEEK_STATUS_OK) {
+					if(e->write_cb(e, b, 5, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+				} else { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+			}
+			if(ok) {
+				put_be(b, si->min_framesize, 3); put_be(b + 3, si->max_framesize, 3);
+				if((ss = e->seek_cb(e, e->streaminfo_offset + 8, e->client_data)) == FLAC__STREAM_ENCODER_SEEK_STATUS_OK) {
+					if(e->write_cb(e, b, 6, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+				} else if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+			}
+			if(e->state != FLAC__STREAM_ENCODER_OK) error = 1;
+		}
+		if(e->metadata_cb) e->metadata_cb(e, &e->streaminfo, e->client_data);
+	}
+	else error = 1;
+	if(e->file) { if(e->file != stdout) fclose(e->file); e->file = 0; }
+	free_buffers(e);
+	{
+		const FLAC__StreamEncoderState st = e->state;
+		set_defaults(e);
+		if(error) e->state = st == FLAC__STREAM_ENCODER_OK ? FLAC__STREAM_ENCODER_CLIENT_ERROR : st; /* :1372-1376: the state survives a failed finish */
+	}
+	return !error;
+}

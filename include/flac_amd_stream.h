@@ -1,0 +1,165 @@
+/* libFLAC-style stream encoder object over the gfx950 frame engine.
+ *
+ * The functions below have the names, argument meaning and error behaviour of the
+ * reference's public encoder API (include/FLAC/stream_encoder.h:693-1760, defined in
+ * src/libFLAC/stream_encoder.c:529-2105), so a client written against the reference
+ * recompiles against this header and links libflacamd.so instead of libFLAC.  What changes
+ * behind the API: blocks are queued on the host, whole batches of frames are coded by the
+ * HIP engine (include/flac_amd_engine.h), and the reference's per-frame write_frame_ logic
+ * (stream_encoder.c:2431-2518) is then replayed frame by frame in stream order, so the
+ * client sees the same callbacks with the same arguments in the same order, only later
+ * (when a batch fills, or at finish()).
+ *
+ * Not provided in this version (calls fail, nothing is silently ignored): Ogg transport
+ * (init_ogg_*), verify mode, user metadata blocks.  set_do_escape_coding and
+ * set_rice_parameter_search_dist are accepted and have no effect, exactly as in the
+ * reference (stream_encoder.c:1635-1649, :1684-1698).
+ */
+#ifndef FLAC_AMD_STREAM_H
+#define FLAC_AMD_STREAM_H
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int FLAC__bool;
+typedef uint8_t FLAC__byte;
+typedef int32_t FLAC__int32;
+typedef uint32_t FLAC__uint32;
+typedef uint64_t FLAC__uint64;
+
+/* values and order of include/FLAC/stream_encoder.h:240-278 */
+typedef enum {
+	FLAC__STREAM_ENCODER_OK = 0,
+	FLAC__STREAM_ENCODER_UNINITIALIZED,
+	FLAC__STREAM_ENCODER_OGG_ERROR,
+	FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR,
+	FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA,
+	FLAC__STREAM_ENCODER_CLIENT_ERROR,
+	FLAC__STREAM_ENCODER_IO_ERROR,
+	FLAC__STREAM_ENCODER_FRAMING_ERROR,
+	FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR
+} FLAC__StreamEncoderState;
+
+/* include/FLAC/stream_encoder.h:292-345 */
+typedef enum {
+	FLAC__STREAM_ENCODER_INIT_STATUS_OK = 0,
+	FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR,
+	FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_NUMBER_OF_CHANNELS,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BITS_PER_SAMPLE,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_SAMPLE_RATE,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_BLOCK_SIZE,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_MAX_LPC_ORDER,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_QLP_COEFF_PRECISION,
+	FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER,
+	FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE,
+	FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA,
+	FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED
+} FLAC__StreamEncoderInitStatus;
+
+typedef enum { FLAC__STREAM_ENCODER_WRITE_STATUS_OK = 0, FLAC__STREAM_ENCODER_WRITE_STATUS_FATAL_ERROR } FLAC__StreamEncoderWriteStatus;
+typedef enum { FLAC__STREAM_ENCODER_SEEK_STATUS_OK, FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR, FLAC__STREAM_ENCODER_SEEK_STATUS_UNSUPPORTED } FLAC__StreamEncoderSeekStatus;
+typedef enum { FLAC__STREAM_ENCODER_TELL_STATUS_OK, FLAC__STREAM_ENCODER_TELL_STATUS_ERROR, FLAC__STREAM_ENCODER_TELL_STATUS_UNSUPPORTED } FLAC__StreamEncoderTellStatus;
+
+extern const char * const FLAC__StreamEncoderStateString[];
+extern const char * const FLAC__StreamEncoderInitStatusString[];
+
+/* The STREAMINFO block as handed to the metadata callback: same leading layout as the
+ * reference's FLAC__StreamMetadata with the stream_info member of its union
+ * (include/FLAC/format.h:527-548, :822-850). */
+typedef struct {
+	unsigned min_blocksize, max_blocksize;
+	unsigned min_framesize, max_framesize;
+	unsigned sample_rate, channels, bits_per_sample;
+	FLAC__uint64 total_samples;
+	FLAC__byte md5sum[16];
+} FLAC__StreamMetadata_StreamInfo;
+
+typedef struct {
+	int type;            /* 0 = STREAMINFO */
+	FLAC__bool is_last;
+	unsigned length;
+	union { FLAC__StreamMetadata_StreamInfo stream_info; uint64_t reserve_[32]; } data;
+} FLAC__StreamMetadata;
+
+typedef struct FLAC__StreamEncoder FLAC__StreamEncoder;
+
+/* include/FLAC/stream_encoder.h:518-677 */
+typedef FLAC__StreamEncoderWriteStatus (*FLAC__StreamEncoderWriteCallback)(const FLAC__StreamEncoder *encoder, const FLAC__byte buffer[], size_t bytes, unsigned samples, unsigned current_frame, void *client_data);
+typedef FLAC__StreamEncoderSeekStatus (*FLAC__StreamEncoderSeekCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 absolute_byte_offset, void *client_data);
+typedef FLAC__StreamEncoderTellStatus (*FLAC__StreamEncoderTellCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 *absolute_byte_offset, void *client_data);
+typedef void (*FLAC__StreamEncoderMetadataCallback)(const FLAC__StreamEncoder *encoder, const FLAC__StreamMetadata *metadata, void *client_data);
+typedef void (*FLAC__StreamEncoderProgressCallback)(const FLAC__StreamEncoder *encoder, FLAC__uint64 bytes_written, FLAC__uint64 samples_written, unsigned frames_written, unsigned total_frames_estimate, void *client_data);
+
+FLAC__StreamEncoder *FLAC__stream_encoder_new(void);
+void FLAC__stream_encoder_delete(FLAC__StreamEncoder *encoder);
+
+/* setters: legal only before init, return false afterwards (stream_encoder.c:1430-1745) */
+FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value); /* true is refused */
+FLAC__bool FLAC__stream_encoder_set_streamable_subset(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_channels(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_bits_per_sample(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_sample_rate(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_blocksize(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_do_mid_side_stereo(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_loose_mid_side_stereo(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *encoder, const char *specification);
+FLAC__bool FLAC__stream_encoder_set_max_lpc_order(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_qlp_coeff_precision(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_do_qlp_coeff_prec_search(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_do_escape_coding(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_do_exhaustive_model_search(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_min_residual_partition_order(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_max_residual_partition_order(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_rice_parameter_search_dist(FLAC__StreamEncoder *encoder, unsigned value);
+FLAC__bool FLAC__stream_encoder_set_total_samples_estimate(FLAC__StreamEncoder *encoder, FLAC__uint64 value);
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *encoder, FLAC__StreamMetadata **metadata, unsigned num_blocks); /* only (NULL, 0) */
+/* semi-private hooks used by the reference's tools (stream_encoder.c:1419, :1747-1778) */
+FLAC__bool FLAC__stream_encoder_disable_constant_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_disable_fixed_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_disable_verbatim_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_set_do_md5(FLAC__StreamEncoder *encoder, FLAC__bool value);
+
+FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *encoder);
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_verify(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_streamable_subset(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_channels(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_bits_per_sample(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_sample_rate(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_blocksize(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_mid_side_stereo(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_loose_mid_side_stereo(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_max_lpc_order(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_qlp_coeff_precision(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_qlp_coeff_prec_search(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_escape_coding(const FLAC__StreamEncoder *encoder);
+FLAC__bool FLAC__stream_encoder_get_do_exhaustive_model_search(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_min_residual_partition_order(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_max_residual_partition_order(const FLAC__StreamEncoder *encoder);
+unsigned FLAC__stream_encoder_get_rice_parameter_search_dist(const FLAC__StreamEncoder *encoder);
+FLAC__uint64 FLAC__stream_encoder_get_total_samples_estimate(const FLAC__StreamEncoder *encoder);
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *encoder, FLAC__StreamEncoderWriteCallback write_callback, FLAC__StreamEncoderSeekCallback seek_callback, FLAC__StreamEncoderTellCallback tell_callback, FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *encoder, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *encoder, const char *filename, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+
+FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *encoder, const FLAC__int32 * const buffer[], unsigned samples);
+FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *encoder, const FLAC__int32 buffer[], unsigned samples);
+FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *encoder);
+
+/* ---- additions of this implementation (no counterpart in the reference) ---- */
+/* HIP device to run on (default 0) and frames per engine batch (default 1024). */
+FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *encoder, int device);
+FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *encoder, unsigned frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -17,14 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(flacamd_[a-z0-9_]+|FLAC__[A-Za-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(flacamd_[a-z0-9_]+|FLAC__[A-Za-z0-9_]+)\s*\((?!\*)", text)))
 
 
 def test_library_exports_every_declared_symbol():
     lib = C.CDLL(engine.LIB_PATH)
     names = _declared_symbols("flac_amd_engine.h")
     assert len(names) >= 20
-    for n in names:
+    stream_names = _declared_symbols("flac_amd_stream.h")
+    assert len(stream_names) >= 50 and "FLAC__stream_encoder_process_interleaved" in stream_names
+    for n in names + stream_names + ["FLAC__StreamEncoderStateString", "FLAC__StreamEncoderInitStatusString"]:
         assert hasattr(lib, n), n
 
 
@@ -74,3 +76,70 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     with pytest.raises(engine.EngineError) as ei:
         engine.Encoder(p, max_frames=4)
     assert ei.value.code == -3
+
+
+# ---- the libFLAC-style object: everything up to the point where a device is needed ----------
+
+def test_stream_encoder_defaults_setters_and_getters():
+    from flac_amd import stream
+    e = stream.StreamEncoder()
+    # set_defaults_ (stream_encoder.c:2107-2160) followed by compression level 5
+    assert e.get_state() == stream.UNINITIALIZED and e.get_resolved_state_string() == "FLAC__STREAM_ENCODER_UNINITIALIZED"
+    assert (e.get_channels(), e.get_bits_per_sample(), e.get_sample_rate(), e.get_blocksize()) == (2, 16, 44100, 0)
+    assert (e.get_streamable_subset(), e.get_verify(), e.get_do_mid_side_stereo(), e.get_loose_mid_side_stereo()) == (1, 0, 1, 0)
+    assert (e.get_max_lpc_order(), e.get_qlp_coeff_precision(), e.get_max_residual_partition_order()) == (8, 0, 5)
+    fp, _ = ob.make_params(2, 16, 44100, level=0)
+    for lvl in range(11):
+        assert e.set_compression_level(lvl)
+        fp, _ = ob.make_params(2, 16, 44100, level=min(lvl, 8))
+        got = (e.get_do_mid_side_stereo(), e.get_loose_mid_side_stereo(), e.get_max_lpc_order(), e.get_qlp_coeff_precision(),
+               e.get_do_qlp_coeff_prec_search(), e.get_do_exhaustive_model_search(), e.get_min_residual_partition_order(),
+               e.get_max_residual_partition_order())
+        want = (fp.do_mid_side, fp.loose_mid_side, fp.max_lpc_order, fp.qlp_coeff_precision, fp.do_qlp_coeff_prec_search,
+                fp.do_exhaustive_model_search, fp.min_residual_partition_order, fp.max_residual_partition_order)
+        assert got == want, lvl
+    assert e.set_channels(3) and e.get_channels() == 3
+    assert e.set_blocksize(576) and e.get_blocksize() == 576
+    assert e.set_total_samples_estimate(1 << 34) and e.get_total_samples_estimate() == 1 << 34
+    # accepted and inert, as in the reference (stream_encoder.c:1635-1649, :1684-1698)
+    assert e.set_do_escape_coding(1) and e.get_do_escape_coding() == 0
+    assert e.set_rice_parameter_search_dist(3) and e.get_rice_parameter_search_dist() == 0
+    assert not e.set_verify(1) and e.set_verify(0)
+    assert e.set_apodization("hann;tukey(0.25);nonsense;gauss(0.2)")
+    assert e.finish()  # finish on an uninitialised encoder is a successful no-op (:1314-1315)
+    e.close()
+
+
+@pytest.mark.parametrize("setup,status", [
+    (dict(channels=0), 4), (dict(channels=9), 4), (dict(bits_per_sample=3), 5), (dict(bits_per_sample=25), 5),
+    (dict(sample_rate=0), 6), (dict(sample_rate=655351), 6), (dict(blocksize=15), 7), (dict(blocksize=65536), 7),
+    (dict(max_lpc_order=33), 8), (dict(blocksize=16, max_lpc_order=17, streamable_subset=0), 10),
+    (dict(qlp_coeff_precision=4), 9), (dict(qlp_coeff_precision=16), 9),
+    (dict(blocksize=4609), 11), (dict(sample_rate=96000, blocksize=16385), 11), (dict(sample_rate=65537), 11),
+    (dict(bits_per_sample=17), 11), (dict(max_residual_partition_order=9), 11), (dict(max_lpc_order=13), 11),
+])
+def test_stream_encoder_init_status_codes(setup, status):
+    """The order and the codes of init_stream_internal_'s checks (stream_encoder.c:656-766)."""
+    from flac_amd import stream
+    e = stream.MemoryEncoder()
+    for k, v in setup.items():
+        assert getattr(e, "set_" + k)(v)
+    assert e.init() == status
+    assert e.get_state() == stream.UNINITIALIZED and e.writes == []
+    e.close()
+
+
+def test_stream_encoder_requires_a_write_callback_and_a_device():
+    from flac_amd import stream
+    L = engine.lib()
+    e = stream.StreamEncoder()
+    assert L.FLAC__stream_encoder_init_stream(e._h, stream.WRITE_CB(), stream.SEEK_CB(), stream.TELL_CB(), stream.META_CB(), None) == 3
+    cb = stream.WRITE_CB(lambda *a: 0)
+    assert L.FLAC__stream_encoder_init_stream(e._h, cb, stream.SEEK_CB(lambda *a: 0), stream.TELL_CB(), stream.META_CB(), None) == 3
+    if engine.device_count() == 0:
+        # no silent CPU path: without a HIP device init fails and says so
+        m = stream.MemoryEncoder()
+        assert m.init() == stream.INIT_ENCODER_ERROR and m.get_state() == stream.MEMORY_ALLOCATION_ERROR
+        assert not m.process_interleaved(np.zeros((10, 2), np.int32))
+        m.close()
+    e.close()
