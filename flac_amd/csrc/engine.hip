@@ -270,6 +270,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	{
 		uint32_t words = 0;
 		fa_pack_lds_bytes(&c, &words);
+		if(words < c.slot_bytes / 4u + 2u) words = c.slot_bytes / 4u + 2u;   // x^(32 w) up to a whole frame
 		uint16_t *tab = (uint16_t*)malloc(sizeof(uint16_t) * (1024u + words + 1u));
 		if(!tab) { hipFree(e->arena); free(e); return FLACAMD_E_OUT_OF_MEMORY; }
 		for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }

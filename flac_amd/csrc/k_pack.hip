@@ -18,6 +18,7 @@
 // GF(2) multiply by x^(8*bytes_after) and an XOR reduction).
 #include "engine_types.h"
 #include "residual.h"
+#include <type_traits>
 
 // ---- CRC helpers (polynomials of crc.c:33-121: CRC-8 0x07, CRC-16 0x8005, init 0, MSB first)
 __device__ __forceinline__ uint32_t crc16_byte(uint32_t crc, uint32_t byte)
@@ -51,6 +52,88 @@ __device__ __forceinline__ uint32_t gf16_xpow8(uint32_t nbytes)
 	uint32_t result = 1u, base = 0x0100u;
 	while(nbytes) { if(nbytes & 1u) result = gf16_mul(result, base); base = gf16_mul(base, base); nbytes >>= 1; }
 	return result;
+}
+
+
+// The codes of a frame header that depend on blocksize and sample rate, and its length in
+// bytes (stream_encoder_framing.c:219-364; UTF-8 frame number bitwriter.c:784-832).
+struct FrameHdrFields { uint32_t bs_code, bs_hint, sr_code, sr_hint, bps_code, nbytes; };
+__device__ __forceinline__ FrameHdrFields fa_frame_header_fields(const FaCfg &c, uint32_t n, uint32_t frame_number)
+{
+	FrameHdrFields h;
+	h.bs_hint = 0; h.sr_hint = 0;
+	switch(n) {
+	case 192: h.bs_code = 1; break; case 576: h.bs_code = 2; break; case 1152: h.bs_code = 3; break; case 2304: h.bs_code = 4; break; case 4608: h.bs_code = 5; break;
+	case 256: h.bs_code = 8; break; case 512: h.bs_code = 9; break; case 1024: h.bs_code = 10; break; case 2048: h.bs_code = 11; break; case 4096: h.bs_code = 12; break;
+	case 8192: h.bs_code = 13; break; case 16384: h.bs_code = 14; break; case 32768: h.bs_code = 15; break;
+	default: h.bs_code = h.bs_hint = (n <= 0x100u) ? 6u : 7u; break;
+	}
+	switch(c.rate) {
+	case 88200: h.sr_code = 1; break; case 176400: h.sr_code = 2; break; case 192000: h.sr_code = 3; break; case 8000: h.sr_code = 4; break; case 16000: h.sr_code = 5; break;
+	case 22050: h.sr_code = 6; break; case 24000: h.sr_code = 7; break; case 32000: h.sr_code = 8; break; case 44100: h.sr_code = 9; break; case 48000: h.sr_code = 10; break; case 96000: h.sr_code = 11; break;
+	default:
+		if(c.rate <= 255000u && c.rate % 1000u == 0) h.sr_code = h.sr_hint = 12;
+		else if(c.rate % 10u == 0) h.sr_code = h.sr_hint = 14;
+		else if(c.rate <= 0xffffu) h.sr_code = h.sr_hint = 13;
+		else h.sr_code = 0;
+		break;
+	}
+	switch(c.bps) { case 8: h.bps_code = 1; break; case 12: h.bps_code = 2; break; case 16: h.bps_code = 4; break; case 20: h.bps_code = 5; break; case 24: h.bps_code = 6; break; default: h.bps_code = 0; break; }
+	const uint32_t v = frame_number;
+	const uint32_t utf8 = v < 0x80u ? 1u : v < 0x800u ? 2u : v < 0x10000u ? 3u : v < 0x200000u ? 4u : v < 0x4000000u ? 5u : 6u;
+	h.nbytes = 4u + utf8 + (h.bs_hint == 6 ? 1u : h.bs_hint == 7 ? 2u : 0u) + (h.sr_hint == 12 ? 1u : h.sr_hint ? 2u : 0u) + 1u;
+	return h;
+}
+
+// The bytes of the frame header including its CRC-8, handed one by one to put(index, byte);
+// returns their count (<= 16).
+template<class PUT>
+__device__ __forceinline__ uint32_t fa_frame_header(const FaCfg &c, uint32_t n, uint32_t frame_number, uint32_t assignment, PUT &&put)
+{
+	const FrameHdrFields h = fa_frame_header_fields(c, n, frame_number);
+	const uint32_t ch_code = (assignment == 0) ? c.channels - 1u : 7u + assignment;
+	uint32_t nb = 0, crc = 0;
+	auto hb = [&](uint32_t byte) { byte &= 0xffu; crc = crc8_byte(crc, byte); put(nb, byte); nb++; };
+	hb(0xff); hb(0xf8); hb((h.bs_code << 4) | h.sr_code); hb((ch_code << 4) | (h.bps_code << 1));
+	{
+		const uint32_t v = frame_number;
+		if(v < 0x80u) hb(v);
+		else if(v < 0x800u) { hb(0xC0u | (v >> 6)); hb(0x80u | (v & 0x3Fu)); }
+		else if(v < 0x10000u) { hb(0xE0u | (v >> 12)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+		else if(v < 0x200000u) { hb(0xF0u | (v >> 18)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+		else if(v < 0x4000000u) { hb(0xF8u | (v >> 24)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+		else { hb(0xFCu | (v >> 30)); hb(0x80u | ((v >> 24) & 0x3Fu)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
+	}
+	if(h.bs_hint == 6) hb(n - 1u);
+	else if(h.bs_hint == 7) { hb((n - 1u) >> 8); hb(n - 1u); }
+	if(h.sr_hint == 12) hb(c.rate / 1000u);
+	else if(h.sr_hint == 13) { hb(c.rate >> 8); hb(c.rate); }
+	else if(h.sr_hint == 14) { hb((c.rate / 10u) >> 8); hb(c.rate / 10u); }
+	hb(crc);
+	return nb;
+}
+
+// Channel assignment of frame f (stream_encoder.c:3052-3087; loose rule :2958-2967, :3059-3061).
+__device__ __forceinline__ uint32_t fa_assignment(const FaCfg &c, const FaWork &w, uint32_t f)
+{
+	uint32_t a = 0;
+	if(c.midside) {
+		const uint32_t fa = c.first_frame + f;
+		const uint32_t cnt = c.loose ? fa % c.loose_period : 0u;
+		// frame whose four estimates decide: this one, or the first of its decision period
+		uint32_t decide_ok = 1, fd = f;
+		if(cnt != 0) { if(cnt <= f) fd = f - cnt; else decide_ok = 0; }
+		if(decide_ok) {
+			const FaWinner *wn = &w.winner[(size_t)fd * 4u];
+			const uint32_t b0 = wn[0].hdr[1], b1 = wn[1].hdr[1], b2 = wn[2].hdr[1], b3 = wn[3].hdr[1];
+			const uint32_t bits[4] = { b0 + b1, b0 + b3, b1 + b3, b2 + b3 };
+			uint32_t m = bits[0];
+			for(uint32_t i = 1; i < 4; i++) if(bits[i] < m) { m = bits[i]; a = i; }
+		}
+		else a = c.prev_assignment;
+		if(cnt != 0) a = (a == 0) ? 0u : 3u; // followers only choose between independent and mid/side
+	}
+	return a;
 }
 
 struct PackShared {
@@ -117,28 +200,28 @@ struct BitRun {
 };
 
 // CRC-16 of n 32-bit big-endian words starting at p, register starting at 0 (slice by four)
-__device__ __forceinline__ uint32_t crc16_words(const uint32_t *p, uint32_t n, const PackShared &sh)
+__device__ __forceinline__ uint32_t crc16_words(const uint32_t *p, uint32_t n, const uint16_t (&t)[4][256])
 {
 	uint32_t crc = 0;
 	for(uint32_t i = 0; i < n; i++) {
 		const uint32_t v = p[i] ^ (crc << 16);
-		crc = (uint32_t)sh.crc4[3][v >> 24] ^ (uint32_t)sh.crc4[2][(v >> 16) & 255u] ^ (uint32_t)sh.crc4[1][(v >> 8) & 255u] ^ (uint32_t)sh.crc4[0][v & 255u];
+		crc = (uint32_t)t[3][v >> 24] ^ (uint32_t)t[2][(v >> 16) & 255u] ^ (uint32_t)t[1][(v >> 8) & 255u] ^ (uint32_t)t[0][v & 255u];
 	}
 	return crc;
 }
 
 // Flush the completed words of the bit buffer (bits [0, total_bits)) to the slot, fold them
 // into the running CRC-16, and keep the partial word as the new carry.  All threads call it.
-__device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bits, uint32_t *slot_words, PackShared &sh, const FaWork &w, uint32_t segw)
+__device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bits, uint32_t *slot_words, PackShared &sh, const FaWork &w, uint32_t segw, uint32_t dbg)
 {
 	const uint32_t full = total_bits >> 5, wo = sh.words_out, tid = threadIdx.x;
 	__syncthreads();
-	for(uint32_t i = tid; i < full; i += 256) slot_words[wo + i] = __builtin_bswap32(bitbuf[i]);
+	if(!(dbg & 0x100u)) for(uint32_t i = tid; i < full; i += 256) slot_words[wo + i] = __builtin_bswap32(bitbuf[i]);
 	// CRC of the chunk: thread j takes the segw words that end segw*j words before the end
-	{
+	if(!(dbg & 0x20u)) {
 		const uint32_t e1 = (segw * tid < full) ? full - segw * tid : 0u, b0 = (e1 > segw) ? e1 - segw : 0u;
 		uint32_t crc = 0;
-		if(e1 > 0) crc = gf16_mul(crc16_words(bitbuf + b0, e1 - b0, sh), w.crc16_xpw[segw * tid]);
+		if(e1 > 0) crc = gf16_mul(crc16_words(bitbuf + b0, e1 - b0, sh.crc4), w.crc16_xpw[segw * tid]);
 #pragma unroll
 		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
 		if((tid & 63u) == 0 && crc) atomicXor(&sh.crc_chunk, crc);
@@ -177,69 +260,16 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 
 	// ---- channel assignment (stream_encoder.c:3052-3087; loose rule :2958-2967, :3059-3061)
 	if(tid == 0) {
-		uint32_t a = 0;
-		if(c.midside) {
-			const uint32_t fa = c.first_frame + f;
-			const uint32_t cnt = c.loose ? fa % c.loose_period : 0u;
-			// frame whose four estimates decide: this one, or the first of its decision period
-			uint32_t decide_ok = 1, fd = f;
-			if(cnt != 0) { if(cnt <= f) fd = f - cnt; else decide_ok = 0; }
-			if(decide_ok) {
-				const FaWinner *wn = &w.winner[(size_t)fd * 4u];
-				const uint32_t b0 = wn[0].hdr[1], b1 = wn[1].hdr[1], b2 = wn[2].hdr[1], b3 = wn[3].hdr[1];
-				const uint32_t bits[4] = { b0 + b1, b0 + b3, b1 + b3, b2 + b3 };
-				uint32_t m = bits[0];
-				for(uint32_t i = 1; i < 4; i++) if(bits[i] < m) { m = bits[i]; a = i; }
-			}
-			else a = c.prev_assignment;
-			if(cnt != 0) a = (a == 0) ? 0u : 3u; // followers only choose between independent and mid/side
-		}
+		const uint32_t a = fa_assignment(c, w, f);
 		sh.assignment = a; sh.carry_bits = 0; sh.words_out = 0; sh.overflow = 0; sh.crc = 0; sh.crc_chunk = 0;
 		w.assignment[f] = a;
 
 		// ---- frame header (stream_encoder_framing.c:219-364), built by one lane
-		uint32_t bs_code, bs_hint = 0, sr_code, sr_hint = 0;
-		switch(n) {
-		case 192: bs_code = 1; break; case 576: bs_code = 2; break; case 1152: bs_code = 3; break; case 2304: bs_code = 4; break; case 4608: bs_code = 5; break;
-		case 256: bs_code = 8; break; case 512: bs_code = 9; break; case 1024: bs_code = 10; break; case 2048: bs_code = 11; break; case 4096: bs_code = 12; break;
-		case 8192: bs_code = 13; break; case 16384: bs_code = 14; break; case 32768: bs_code = 15; break;
-		default: bs_code = bs_hint = (n <= 0x100u) ? 6u : 7u; break;
-		}
-		switch(c.rate) {
-		case 88200: sr_code = 1; break; case 176400: sr_code = 2; break; case 192000: sr_code = 3; break; case 8000: sr_code = 4; break; case 16000: sr_code = 5; break;
-		case 22050: sr_code = 6; break; case 24000: sr_code = 7; break; case 32000: sr_code = 8; break; case 44100: sr_code = 9; break; case 48000: sr_code = 10; break; case 96000: sr_code = 11; break;
-		default:
-			if(c.rate <= 255000u && c.rate % 1000u == 0) sr_code = sr_hint = 12;
-			else if(c.rate % 10u == 0) sr_code = sr_hint = 14;
-			else if(c.rate <= 0xffffu) sr_code = sr_hint = 13;
-			else sr_code = 0;
-			break;
-		}
-		uint32_t bps_code;
-		switch(c.bps) { case 8: bps_code = 1; break; case 12: bps_code = 2; break; case 16: bps_code = 4; break; case 20: bps_code = 5; break; case 24: bps_code = 6; break; default: bps_code = 0; break; }
-		const uint32_t ch_code = (a == 0) ? c.channels - 1u : 7u + a;
-		uint32_t nb = 0, crc = 0;
-		auto hb = [&](uint32_t byte) { byte &= 0xffu; crc = crc8_byte(crc, byte); bitbuf[nb >> 2] |= byte << (24u - 8u * (nb & 3u)); nb++; };
-		hb(0xff); hb(0xf8); hb((bs_code << 4) | sr_code); hb((ch_code << 4) | (bps_code << 1));
-		{ // frame number, bitwriter.c:784-832
-			const uint32_t v = c.first_frame + f;
-			if(v < 0x80u) hb(v);
-			else if(v < 0x800u) { hb(0xC0u | (v >> 6)); hb(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x10000u) { hb(0xE0u | (v >> 12)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x200000u) { hb(0xF0u | (v >> 18)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
-			else if(v < 0x4000000u) { hb(0xF8u | (v >> 24)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
-			else { hb(0xFCu | (v >> 30)); hb(0x80u | ((v >> 24) & 0x3Fu)); hb(0x80u | ((v >> 18) & 0x3Fu)); hb(0x80u | ((v >> 12) & 0x3Fu)); hb(0x80u | ((v >> 6) & 0x3Fu)); hb(0x80u | (v & 0x3Fu)); }
-		}
-		if(bs_hint == 6) hb(n - 1u);
-		else if(bs_hint == 7) { hb((n - 1u) >> 8); hb(n - 1u); }
-		if(sr_hint == 12) hb(c.rate / 1000u);
-		else if(sr_hint == 13) { hb(c.rate >> 8); hb(c.rate); }
-		else if(sr_hint == 14) { hb((c.rate / 10u) >> 8); hb(c.rate / 10u); }
-		hb(crc);
+		const uint32_t nb = fa_frame_header(c, n, c.first_frame + f, a, [&](uint32_t i, uint32_t byte) { bitbuf[i >> 2] |= byte << (24u - 8u * (i & 3u)); });
 		sh.hdr_bytes = nb;
 	}
 	__syncthreads();
-	flush_words(bitbuf, sh.hdr_bytes * 8u, slot_words, sh, w, segw);
+	flush_words(bitbuf, sh.hdr_bytes * 8u, slot_words, sh, w, segw, c.debug);
 
 	const uint32_t assignment = sh.assignment;
 	const uint32_t nsub = c.channels;
@@ -261,7 +291,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		// stage the signal and the winner's parameters
 		{
 			const uint32_t nup = (n + CH - 1u) & ~(CH - 1u);
-			for(uint32_t i = tid; i < nup; i += 256) xs[xs_idx((int32_t)i)] = (i < n) ? (fa_signal(pcm, c, sig, base + i) >> wasted) : 0;
+			if(!(c.debug & 0x200u)) for(uint32_t i = tid; i < nup; i += 256) xs[xs_idx((int32_t)i)] = (i < n) ? (fa_signal(pcm, c, sig, base + i) >> wasted) : 0;
 		}
 		if(tid < FLACAMD_MAX_LPC_ORDER) sh.q[tid] = win->q[tid];
 		if(type >= FA_SUB_FIXED) for(uint32_t p = tid; p < (1u << po); p += 256) sh.k[p] = win->k[p];
@@ -277,7 +307,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		const uint32_t smask = sbps < 32u ? (1u << sbps) - 1u : 0xffffffffu;
 
 		// ---- head (one lane; a few dozen tokens)
-		if(tid == 0 && carry + head_bits <= cap_bits) {
+		if(tid == 0 && carry + head_bits <= cap_bits && !(c.debug & 0x40u)) {
 			BitRun br; br.begin(bitbuf, carry);
 			uint32_t tb;
 			switch(type) { // stream_encoder_framing.c:371, :383, :421, :468
@@ -314,7 +344,11 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 				}
 				else {
 					int32_t res[CH];
-					if(order <= HIST) {
+					if(c.debug & 0x80u) {
+#pragma unroll
+						for(int s = 0; s < CH; s++) res[s] = (int32_t)((i0 + s) & 7u);
+					}
+					else if(order <= HIST) {
 						int32_t xw[HIST + CH];
 #pragma unroll
 						for(int j = 0; j < HIST + CH; j++) xw[j] = xs[xs_idx((int32_t)i0 - HIST + j)];
@@ -354,7 +388,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 			uint32_t round_bits;
 			const uint32_t myoff = block_exscan(mybits, sh, round_bits);
 			if(bitpos + round_bits > cap_bits) { ovf = true; break; }
-			if(mybits) {
+			if(mybits && !(c.debug & 0x10u)) {
 				BitRun br; br.begin(bitbuf, bitpos + myoff);
 				if(type <= FA_SUB_VERBATIM) {
 #pragma unroll
@@ -378,7 +412,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 			__syncthreads();
 			break;
 		}
-		flush_words(bitbuf, bitpos, slot_words, sh, w, segw);
+		flush_words(bitbuf, bitpos, slot_words, sh, w, segw, c.debug);
 	}
 
 	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905)
@@ -390,6 +424,347 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		for(uint32_t i = 0; i < tail_bytes; i++) {
 			const uint32_t byte = (bitbuf[0] >> (24u - 8u * i)) & 0xffu;
 			slot[sh.words_out * 4u + i] = (uint8_t)byte;
+			crc = ((crc << 8) & 0xffffu) ^ sh.crc4[0][(crc >> 8) ^ byte];
+		}
+		slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc;
+		w.frame_bytes[f] = body_bytes + 2u;
+	}
+}
+
+// ---- fast path: mono / stereo streams, blocksize <= 4096, predictor orders <= HIST ----------
+//
+// One 512-thread workgroup per frame, 8 samples per thread, every subframe of the frame in
+// the same pass.  Nothing depends on a previous step's global load: the winners' headers are
+// read first (wave-uniform), then every thread fetches its 8 + HIST wide samples straight
+// from the interleaved PCM into registers (no LDS copy of the signal) together with its Rice
+// parameter, forms the signals it needs (left/right/mid/side) from the same registers,
+// computes residual tokens and their bit lengths, and ONE workgroup scan over (bits of
+// subframe 0, bits of subframe 1) places every token of the frame.  The subframe heads
+// (type, warm-up samples, coefficients) are written token-parallel by the first wave.  The
+// whole frame is assembled in LDS and flushed once: coalesced word stores, CRC-16 per thread
+// segment folded with x^(32 w) multipliers.  Four barriers per frame.
+#define PF_THREADS 512
+#define PF_CH 8
+#define PF_W (HIST + PF_CH)
+
+struct PackFastShared {
+	uint32_t wave_tot[PF_THREADS / 64][2];
+	uint32_t crc_acc;
+	uint16_t crc4[4][256];
+};
+
+struct SubDesc { uint32_t type, order, prec, shift, po, rice2, wasted, wide, sbps, sig, g, head_bits, nwarm; };
+
+// OR a token into the bit buffer where any word may be shared with other writers
+__device__ __forceinline__ void put_shared(uint32_t *buf, uint32_t pos, uint32_t v, uint32_t nbits)
+{
+	const uint32_t off = pos & 31u, wi = pos >> 5;
+	if(off + nbits <= 32u) atomicOr(&buf[wi], v << (32u - off - nbits));
+	else { const uint32_t spill = off + nbits - 32u; atomicOr(&buf[wi], v >> spill); atomicOr(&buf[wi + 1u], v << (32u - spill)); }
+}
+
+// four consecutive wide samples starting at batch sample `wide` (a multiple of 4) into a[4], b[4]
+// (channel 0 and channel 1); samples at or past `end` read as zero
+template<int NSUB>
+__device__ __forceinline__ void pf_load4(const void *__restrict__ pcm, uint32_t fmt, uint64_t wide, uint64_t end, int32_t (&a)[4], int32_t (&b)[4])
+{
+	if(wide + 4u <= end) {
+		if(NSUB == 2) {
+			if(fmt == FLACAMD_PCM_S16) {
+				const uint4 v = *(const uint4*)((const uint32_t*)pcm + wide);
+				const uint32_t t[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+				for(int j = 0; j < 4; j++) { a[j] = (int32_t)(int16_t)(t[j] & 0xffffu); b[j] = (int32_t)t[j] >> 16; }
+			}
+			else {
+				const uint4 v0 = *(const uint4*)((const int32_t*)pcm + wide * 2u), v1 = *(const uint4*)((const int32_t*)pcm + wide * 2u + 4u);
+				a[0] = (int32_t)v0.x; b[0] = (int32_t)v0.y; a[1] = (int32_t)v0.z; b[1] = (int32_t)v0.w;
+				a[2] = (int32_t)v1.x; b[2] = (int32_t)v1.y; a[3] = (int32_t)v1.z; b[3] = (int32_t)v1.w;
+			}
+		}
+		else {
+			if(fmt == FLACAMD_PCM_S16) {
+				const uint2 v = *(const uint2*)((const int16_t*)pcm + wide);
+				a[0] = (int32_t)(int16_t)(v.x & 0xffffu); a[1] = (int32_t)v.x >> 16; a[2] = (int32_t)(int16_t)(v.y & 0xffffu); a[3] = (int32_t)v.y >> 16;
+			}
+			else {
+				const uint4 v = *(const uint4*)((const int32_t*)pcm + wide);
+				a[0] = (int32_t)v.x; a[1] = (int32_t)v.y; a[2] = (int32_t)v.z; a[3] = (int32_t)v.w;
+			}
+#pragma unroll
+			for(int j = 0; j < 4; j++) b[j] = 0;
+		}
+	}
+	else {
+#pragma unroll
+		for(int j = 0; j < 4; j++) {
+			const bool ok = wide + (uint64_t)j < end;
+			a[j] = ok ? fa_pcm(pcm, fmt, NSUB, wide + j, 0) : 0;
+			b[j] = (ok && NSUB == 2) ? fa_pcm(pcm, fmt, NSUB, wide + j, 1) : 0;
+		}
+	}
+}
+
+template<int NSUB>
+__global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	__shared__ PackFastShared sh;
+	uint32_t *bitbuf = (uint32_t*)lds_raw;
+
+	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t n = fa_frame_len(c, f);
+	const uint64_t base = (uint64_t)f * c.N;
+	uint8_t *slot = w.slots + (size_t)f * c.slot_bytes;
+	uint32_t *slot_words = (uint32_t*)slot;
+	const uint32_t cap_bits = (bitbuf_words - 2u) * 32u;
+	const uint32_t i0 = tid * PF_CH;
+
+	for(uint32_t i = tid; i < bitbuf_words; i += PF_THREADS) bitbuf[i] = 0;
+	if(tid < 512u) ((uint32_t*)sh.crc4)[tid] = ((const uint32_t*)w.crc16_table4)[tid];
+	if(tid == 0) sh.crc_acc = 0;
+
+	// ---- wave-uniform decisions: assignment, the winner of every subframe
+	const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)fa_assignment(c, w, f));
+	if(tid == 0) w.assignment[f] = a;
+	SubDesc d[NSUB];
+#pragma unroll
+	for(int sc = 0; sc < NSUB; sc++) {
+		uint32_t sig = (uint32_t)sc;
+		if(c.midside) { // stream_encoder.c:3096-3115
+			if(a == 1) sig = sc == 0 ? 0u : 3u;
+			else if(a == 2) sig = sc == 0 ? 3u : 1u;
+			else if(a == 3) sig = sc == 0 ? 2u : 3u;
+		}
+		const uint32_t g = f * c.nsig + sig;
+		const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.winner[g].hdr[0]);
+		SubDesc &s = d[sc];
+		s.sig = sig; s.g = g;
+		s.sbps = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.winner[g].hdr[2]);
+		s.type = FA_WIN_TYPE(h0); s.order = FA_WIN_ORDER(h0); s.prec = FA_WIN_PREC(h0); s.shift = FA_WIN_SHIFT(h0); s.po = FA_WIN_PO(h0);
+		s.rice2 = FA_WIN_RICE2(h0); s.wasted = FA_WIN_WASTED(h0); s.wide = FA_WIN_WIDE(h0);
+		s.nwarm = s.type == FA_SUB_CONSTANT ? 1u : s.type >= FA_SUB_FIXED ? s.order : 0u;
+		s.head_bits = 8u + s.wasted + s.nwarm * s.sbps + (s.type == FA_SUB_LPC ? 9u + s.order * s.prec : 0u) + (s.type >= FA_SUB_FIXED ? 6u : 0u);
+	}
+	const FrameHdrFields hf = fa_frame_header_fields(c, n, c.first_frame + f);
+
+	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels
+	int32_t xa[PF_W], xb[PF_W];
+	{
+		const uint64_t end = base + n;
+#pragma unroll
+		for(int j = 0; j < PF_W / 4; j++) {
+			int32_t ta[4], tb[4];
+			const int32_t rel = (int32_t)i0 - HIST + 4 * j;
+			if(rel < 0 || (uint32_t)rel >= n) {
+#pragma unroll
+				for(int q = 0; q < 4; q++) { ta[q] = 0; tb[q] = 0; }
+			}
+			else pf_load4<NSUB>(pcm, c.pcm_format, base + (uint32_t)rel, end, ta, tb);
+#pragma unroll
+			for(int q = 0; q < 4; q++) { xa[4 * j + q] = ta[q]; xb[4 * j + q] = tb[q]; }
+		}
+	}
+
+	// ---- tokens of one subframe: folded residuals u[], the Rice parameter of this thread's
+	// partition, where a partition parameter precedes a token, and the bits of the run
+	uint32_t u[NSUB][PF_CH], kk[NSUB], bits[NSUB];
+	int first_s[NSUB];
+	bool bad = false;
+	auto analyse = [&](auto sc_const) {
+		constexpr int sc = decltype(sc_const)::value;
+		const SubDesc &s = d[sc];
+		uint32_t mybits = 0;
+		kk[sc] = 0; first_s[sc] = -1;
+#pragma unroll
+		for(int q = 0; q < PF_CH; q++) u[sc][q] = 0;
+		if(i0 < n && s.type != FA_SUB_CONSTANT) {
+			const uint32_t dps = n >> s.po;
+			if(s.po && (dps % PF_CH)) bad = true;
+			const uint32_t p = s.po ? i0 / dps : 0u;
+			if(s.type >= FA_SUB_FIXED) kk[sc] = w.winner[s.g].k[p];
+			int32_t xw[PF_W];
+#pragma unroll
+			for(int j = 0; j < PF_W; j++) {
+				const int32_t l = xa[j], r = xb[j];
+				int32_t v;
+				if(c.midside) v = s.sig == 0 ? l : s.sig == 1 ? r : s.sig == 2 ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
+				else v = sc == 0 ? l : r;
+				xw[j] = v >> s.wasted;
+			}
+			const uint32_t smask = s.sbps < 32u ? (1u << s.sbps) - 1u : 0xffffffffu;
+			if(s.type == FA_SUB_VERBATIM) {
+#pragma unroll
+				for(int q = 0; q < PF_CH; q++) if(i0 + (uint32_t)q < n) { u[sc][q] = (uint32_t)xw[HIST + q] & smask; mybits += s.sbps; }
+			}
+			else {
+				int32_t res[PF_CH];
+				auto keep = [&](int q, int32_t rv, int) { res[q] = rv; };
+				if(c.debug & 0x80u) {
+#pragma unroll
+					for(int q = 0; q < PF_CH; q++) res[q] = (int32_t)((i0 + q) & 7u);
+				}
+				else if(s.type == FA_SUB_FIXED) fixed_each_dispatch(s.order, xw, keep);
+				else {
+					int32_t qc[HIST];
+#pragma unroll
+					for(int j = 0; j < HIST; j++) qc[j] = __builtin_amdgcn_readfirstlane(w.winner[s.g].q[j]);
+					if(s.wide) lpc_each_dispatch<MAC_WIDE>(s.order, xw, qc, s.shift, keep);
+					else if(s.sbps <= 24) lpc_each_dispatch<MAC_I24>(s.order, xw, qc, s.shift, keep);
+					else lpc_each_dispatch<MAC_I32>(s.order, xw, qc, s.shift, keep);
+				}
+				const uint32_t k = kk[sc];
+				const uint32_t pstart = p ? p * dps : s.order;   // first sample that carries a residual in this partition
+				if(pstart >= i0 && pstart < i0 + PF_CH) { first_s[sc] = (int)(pstart - i0); mybits += s.rice2 ? 5u : 4u; }
+#pragma unroll
+				for(int q = 0; q < PF_CH; q++) {
+					const uint32_t i = i0 + (uint32_t)q;
+					if(i >= s.order && i < n) {
+						const uint32_t uu = ((uint32_t)res[q] << 1) ^ (uint32_t)(res[q] >> 31);
+						u[sc][q] = uu;
+						mybits += (uu >> k) + 1u + k;
+					}
+				}
+			}
+		}
+		bits[sc] = mybits;
+	};
+	analyse(std::integral_constant<int, 0>{});
+	if constexpr(NSUB == 2) analyse(std::integral_constant<int, 1>{});
+
+	// ---- one scan for the whole frame
+	uint32_t ex[NSUB], tot[NSUB];
+	{
+		const uint32_t lane = tid & 63u, wv = tid >> 6;
+		uint32_t inc[NSUB];
+#pragma unroll
+		for(int sc = 0; sc < NSUB; sc++) inc[sc] = bits[sc];
+#pragma unroll
+		for(int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+			for(int sc = 0; sc < NSUB; sc++) { const uint32_t t = (uint32_t)__shfl_up((int)inc[sc], o, 64); if(lane >= (uint32_t)o) inc[sc] += t; }
+		}
+		if(lane == 63u) {
+#pragma unroll
+			for(int sc = 0; sc < NSUB; sc++) sh.wave_tot[wv][sc] = inc[sc];
+		}
+		__syncthreads();   // also orders the zeroing of bitbuf and the table load before their use
+#pragma unroll
+		for(int sc = 0; sc < NSUB; sc++) {
+			uint32_t pre = 0, all = 0;
+#pragma unroll
+			for(uint32_t i = 0; i < PF_THREADS / 64; i++) { const uint32_t t = sh.wave_tot[i][sc]; all += t; if(i < wv) pre += t; }
+			ex[sc] = pre + inc[sc] - bits[sc]; tot[sc] = all;
+		}
+	}
+	uint32_t start[NSUB];   // bit position of the head of each subframe
+	uint32_t total_bits = hf.nbytes * 8u;
+#pragma unroll
+	for(int sc = 0; sc < NSUB; sc++) { start[sc] = total_bits; total_bits += d[sc].head_bits + tot[sc]; }
+	if(total_bits > cap_bits || __syncthreads_or(bad ? 1 : 0)) { // cannot happen for estimates that did not wrap; never write past the buffer
+		if(tid == 0) { atomicOr(w.status, 1u); w.frame_bytes[f] = 0; }
+		return;
+	}
+
+	// ---- frame header (one lane of the last wave), subframe heads (token-parallel, first wave)
+	if(tid == PF_THREADS - 1u) {
+		fa_frame_header(c, n, c.first_frame + f, a, [&](uint32_t i, uint32_t byte) { atomicOr(&bitbuf[i >> 2], byte << (24u - 8u * (i & 3u))); });
+	}
+	if(tid < 32u * NSUB && !(c.debug & 0x40u)) {
+		const uint32_t sc = tid >> 5, t = tid & 31u;
+		// the descriptor of this lane's subframe, selected field by field (an indexed struct would live in scratch)
+		const bool hi = NSUB == 2 && sc == 1u;
+		SubDesc s;
+#define PF_SEL(fld) s.fld = hi ? d[NSUB - 1].fld : d[0].fld
+		PF_SEL(type); PF_SEL(order); PF_SEL(prec); PF_SEL(shift); PF_SEL(po); PF_SEL(rice2); PF_SEL(wasted); PF_SEL(wide); PF_SEL(sbps); PF_SEL(sig); PF_SEL(g); PF_SEL(head_bits); PF_SEL(nwarm);
+#undef PF_SEL
+		const uint32_t pos0 = hi ? start[NSUB - 1] : start[0];
+		const uint32_t wtok = s.wasted ? 1u : 0u;
+		const uint32_t lpc = s.type == FA_SUB_LPC ? 1u : 0u, coded = s.type >= FA_SUB_FIXED ? 1u : 0u;
+		const uint32_t ntok = 1u + wtok + s.nwarm + lpc * (1u + s.order) + coded;
+		if(t < ntok) {
+			uint32_t pos = pos0, v, nb;
+			if(t == 0) { // stream_encoder_framing.c:371, :383, :421, :468
+				uint32_t tb;
+				switch(s.type) { case FA_SUB_CONSTANT: tb = 0x00; break; case FA_SUB_VERBATIM: tb = 0x02; break; case FA_SUB_FIXED: tb = 0x10u | (s.order << 1); break; default: tb = 0x40u | ((s.order - 1u) << 1); break; }
+				v = tb | wtok; nb = 8;
+			}
+			else if(t < 1u + wtok) { pos += 8u; v = 1u; nb = s.wasted; }               // wasted - 1 zeros and a one
+			else if(t < 1u + wtok + s.nwarm) {                                          // warm-up samples (or the constant)
+				const uint32_t j = t - 1u - wtok;
+				pos += 8u + s.wasted + j * s.sbps;
+				const uint64_t wide = base + j;
+				const int32_t l = fa_pcm(pcm, c.pcm_format, NSUB, wide, 0), r = NSUB == 2 ? fa_pcm(pcm, c.pcm_format, NSUB, wide, 1) : 0;
+				int32_t x;
+				if(c.midside) x = s.sig == 0 ? l : s.sig == 1 ? r : s.sig == 2 ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
+				else x = sc == 0 ? l : r;
+				v = (uint32_t)(x >> s.wasted) & (s.sbps < 32u ? (1u << s.sbps) - 1u : 0xffffffffu); nb = s.sbps;
+			}
+			else if(lpc && t == 1u + wtok + s.nwarm) { pos += 8u + s.wasted + s.nwarm * s.sbps; v = ((s.prec - 1u) << 5) | (s.shift & 31u); nb = 9; }
+			else if(lpc && t < 2u + wtok + s.nwarm + s.order) {
+				const uint32_t j = t - 2u - wtok - s.nwarm;
+				pos += 8u + s.wasted + s.nwarm * s.sbps + 9u + j * s.prec;
+				v = (uint32_t)w.winner[s.g].q[j] & ((1u << s.prec) - 1u); nb = s.prec;
+			}
+			else { pos += s.head_bits - 6u; v = (s.rice2 << 4) | s.po; nb = 6; }
+			put_shared(bitbuf, pos, v, nb);
+		}
+	}
+
+	// ---- residual tokens
+	auto emit = [&](auto sc_const) {
+		constexpr int sc = decltype(sc_const)::value;
+		const SubDesc &s = d[sc];
+		if(bits[sc] != 0) {
+			BitRun br; br.begin(bitbuf, start[sc] + s.head_bits + ex[sc]);
+			if(s.type == FA_SUB_VERBATIM) {
+#pragma unroll
+				for(int q = 0; q < PF_CH; q++) if(i0 + (uint32_t)q < n) br.put(u[sc][q], s.sbps);
+			}
+			else {
+				const uint32_t k = kk[sc], plen = s.rice2 ? 5u : 4u;
+#pragma unroll
+				for(int q = 0; q < PF_CH; q++) {
+					const uint32_t i = i0 + (uint32_t)q;
+					if(i >= s.order && i < n) {
+						if(q == first_s[sc]) br.put(k, plen);
+						br.zeros(u[sc][q] >> k);                                          // unary part
+						br.put((1u << k) | (u[sc][q] & ((1u << k) - 1u)), k + 1u);       // stop bit + k low bits
+					}
+				}
+			}
+			br.end();
+		}
+	};
+	if(!(c.debug & 0x10u)) {
+		emit(std::integral_constant<int, 0>{});
+		if constexpr(NSUB == 2) emit(std::integral_constant<int, 1>{});
+	}
+	__syncthreads();
+
+	// ---- flush: whole words to the slot, CRC-16 of thread segments combined with x^(32 w)
+	const uint32_t full = total_bits >> 5;
+	if(!(c.debug & 0x100u)) for(uint32_t i = tid; i < full; i += PF_THREADS) slot_words[i] = __builtin_bswap32(bitbuf[i]);
+	if(!(c.debug & 0x20u)) {
+		const uint32_t segw = (full + PF_THREADS - 1u) / PF_THREADS;
+		const uint32_t e1 = (segw * tid < full) ? full - segw * tid : 0u, b0 = (e1 > segw) ? e1 - segw : 0u;
+		uint32_t crc = 0;
+		if(e1 > 0) crc = gf16_mul(crc16_words(bitbuf + b0, e1 - b0, sh.crc4), w.crc16_xpw[segw * tid]);
+#pragma unroll
+		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
+		if((tid & 63u) == 0 && crc) atomicXor(&sh.crc_acc, crc);
+	}
+	__syncthreads();
+
+	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905)
+	if(tid == 0) {
+		const uint32_t tail_bits = total_bits & 31u, tail_bytes = (tail_bits + 7u) >> 3;
+		const uint32_t body_bytes = full * 4u + tail_bytes;
+		uint32_t crc = sh.crc_acc;
+		const uint32_t last = bitbuf[full];
+		for(uint32_t i = 0; i < tail_bytes; i++) {
+			const uint32_t byte = (last >> (24u - 8u * i)) & 0xffu;
+			slot[full * 4u + i] = (uint8_t)byte;
 			crc = ((crc << 8) & 0xffffu) ^ sh.crc4[0][(crc >> 8) ^ byte];
 		}
 		slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc;
@@ -461,11 +836,39 @@ extern "C" size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out)
 	return ((size_t)xs_words_for(c->N) * 4u + (size_t)words * 4u + 15u) & ~(size_t)15u;
 }
 
+// the fast kernel applies to mono / stereo streams whose blocks fit 512 x 8 samples, whose
+// partitions are whole multiples of a thread's 8 samples and whose predictors fit the register window
+static bool fa_pack_fast_ok(const void *pcm, const FaCfg *c)
+{
+	return c->channels <= 2u && c->N <= (uint32_t)(PF_THREADS * PF_CH) && c->N % ((uint32_t)PF_CH << c->max_po) == 0 && c->max_lpc_order <= (uint32_t)HIST
+		&& ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x400u);
+}
+
+static uint32_t fa_pack_fast_words(const FaCfg *c)
+{
+	const uint32_t maxbps = c->bps + 1u;
+	const size_t sub = (size_t)c->N * (maxbps + 1u) + 8u + 32u + 32u * (maxbps + 15u) + 64u;
+	return (uint32_t)((16u * 8u + c->channels * sub + 64u + 31u) / 32u) + 4u;
+}
+
 extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
+	if(fa_pack_fast_ok(pcm, c)) {
+		const uint32_t words = fa_pack_fast_words(c);
+		const size_t lds = ((size_t)words * 4u + 15u) & ~(size_t)15u;
+		if(c->channels == 2) {
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL(fa_pack_fast_kernel<2>, dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
+		}
+		else {
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL(fa_pack_fast_kernel<1>, dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
+		}
+		return;
+	}
 	uint32_t words = 0;
 	const size_t lds = fa_pack_lds_bytes(c, &words);
-	hipFuncSetAttribute((const void*)fa_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	(void)hipFuncSetAttribute((const void*)fa_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipLaunchKernelGGL(fa_pack_kernel, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);
 }
 

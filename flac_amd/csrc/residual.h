@@ -1,7 +1,8 @@
 // Register-window residual evaluation shared by the search and pack kernels.
 //
-// A thread holds CH consecutive samples of a signal plus HIST samples of history in
-// registers (xw[HIST + s] is sample s of the chunk) and evaluates a predictor on all CH
+// A thread holds a chunk of consecutive samples of a signal (CH in the search kernel, any
+// W - HIST elsewhere) plus HIST samples of history in registers (xw[HIST + s] is sample s of
+// the chunk) and evaluates a predictor on all CH
 // samples with fully unrolled code: coefficients are wave-uniform, every tap is one VALU
 // instruction.  Orders above HIST take the callers' generic per-sample path.
 //
@@ -36,11 +37,11 @@ __device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)
 }
 
 // f(s, r, P): residual r of chunk sample s under an order-P predictor
-template<int P, int MODE, class F>
-__device__ __forceinline__ void lpc_each(const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+template<int P, int MODE, int W, class F>
+__device__ __forceinline__ void lpc_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
 {
 #pragma unroll
-	for(int s = 0; s < CH; s++) {
+	for(int s = 0; s < W - HIST; s++) {
 		int32_t pred;
 		if(MODE == MAC_WIDE) {
 			long long acc = 0;
@@ -64,8 +65,8 @@ __device__ __forceinline__ void lpc_each(const int32_t (&xw)[HIST + CH], const i
 	}
 }
 
-template<int MODE, class F>
-__device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+template<int MODE, int W, class F>
+__device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
 {
 	switch(order) {
 	case 1: lpc_each<1, MODE>(xw, q, shift, f); break;
@@ -84,11 +85,11 @@ __device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t 
 }
 
 // k-th difference, 32-bit wrapping
-template<int K, class F>
-__device__ __forceinline__ void fixed_each(const int32_t (&xw)[HIST + CH], F &&f)
+template<int K, int W, class F>
+__device__ __forceinline__ void fixed_each(const int32_t (&xw)[W], F &&f)
 {
 #pragma unroll
-	for(int s = 0; s < CH; s++) {
+	for(int s = 0; s < W - HIST; s++) {
 		const uint32_t a = (uint32_t)xw[HIST + s], b = (uint32_t)xw[HIST + s - 1], c = (uint32_t)xw[HIST + s - 2], d = (uint32_t)xw[HIST + s - 3], e = (uint32_t)xw[HIST + s - 4];
 		uint32_t r;
 		if(K == 0) r = a; else if(K == 1) r = a - b; else if(K == 2) r = a - 2u*b + c; else if(K == 3) r = a - 3u*b + 3u*c - d; else r = a - 4u*b + 6u*c - 4u*d + e;
@@ -96,8 +97,8 @@ __device__ __forceinline__ void fixed_each(const int32_t (&xw)[HIST + CH], F &&f
 	}
 }
 
-template<class F>
-__device__ __forceinline__ void fixed_each_dispatch(uint32_t order, const int32_t (&xw)[HIST + CH], F &&f)
+template<int W, class F>
+__device__ __forceinline__ void fixed_each_dispatch(uint32_t order, const int32_t (&xw)[W], F &&f)
 {
 	switch(order) {
 	case 0: fixed_each<0>(xw, f); break;
