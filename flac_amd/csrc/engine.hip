@@ -255,7 +255,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_chdr = take((size_t)c.max_cand * G * 4), o_cq = take((size_t)c.max_cand * qrows * G * 4),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes));
+		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
 	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
@@ -264,7 +264,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_chdr); w.cand_q = (int32_t*)(b + o_cq);
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg);
-	w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
+	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
 	{
@@ -423,6 +423,7 @@ extern "C" long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h
 	case 2: break;
 	case 3: break;
 	case 4: src = e->work.wasted; bytes = G; break;
+	case 5: src = e->work.dbg; bytes = (size_t)FA_DBG_WORDS * 8u; break;
 	default: return FLACAMD_E_INVALID_ARGUMENT;
 	}
 	if(what == 2 || what == 3) {

@@ -7,6 +7,7 @@
 #define FA_MIN_QLP_PRECISION 5u
 #define FA_MAX_QLP_PRECISION 15u
 #define FA_MAX_PARTS (1u << FLACAMD_MAX_PARTITION_ORDER)
+#define FA_DBG_WORDS 131072u
 
 // subframe kinds (bitstream order of the type codes)
 enum { FA_SUB_CONSTANT = 0, FA_SUB_VERBATIM = 1, FA_SUB_FIXED = 2, FA_SUB_LPC = 3 };
@@ -100,6 +101,7 @@ struct FaWork {
 	const float *window;   // [num_apod][N]
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial
+	unsigned long long *dbg;      // [FA_DBG_WORDS] development timestamps (FLACAMD_DEBUG & 0x1000), unused in production
 };
 
 #ifdef __HIPCC__

@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 	uint8_t *slot = w.slots + (size_t)f * c.slot_bytes;
 	const uint32_t cap_bits = (bitbuf_words - 2u) * 32u;
 	const uint32_t segw = (bitbuf_words + 255u) / 256u;
+	const uint32_t kspread = c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER;
 
 	for(uint32_t i = tid; i < bitbuf_words; i += 256) bitbuf[i] = 0;
 	if(tid < 32) xs[xs_idx((int32_t)tid - 32)] = 0;
@@ -294,7 +295,8 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 			if(!(c.debug & 0x200u)) for(uint32_t i = tid; i < nup; i += 256) xs[xs_idx((int32_t)i)] = (i < n) ? (fa_signal(pcm, c, sig, base + i) >> wasted) : 0;
 		}
 		if(tid < FLACAMD_MAX_LPC_ORDER) sh.q[tid] = win->q[tid];
-		if(type >= FA_SUB_FIXED) for(uint32_t p = tid; p < (1u << po); p += 256) sh.k[p] = win->k[p];
+		// the winner's Rice parameters are stored spread to the finest configured order
+		if(type >= FA_SUB_FIXED) for(uint32_t p = tid; p < (1u << po); p += 256) sh.k[p] = win->k[p << (kspread - po)];
 		__syncthreads();
 
 		// bits of the subframe head: type byte, wasted-bits unary, warm-up, lpc parameters, coding method + partition order
@@ -519,6 +521,7 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 	uint32_t *slot_words = (uint32_t*)slot;
 	const uint32_t cap_bits = (bitbuf_words - 2u) * 32u;
 	const uint32_t i0 = tid * PF_CH;
+	const uint32_t kspread = c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER;
 
 	for(uint32_t i = tid; i < bitbuf_words; i += PF_THREADS) bitbuf[i] = 0;
 	if(tid < 512u) ((uint32_t*)sh.crc4)[tid] = ((const uint32_t*)w.crc16_table4)[tid];
@@ -582,7 +585,7 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 			const uint32_t dps = n >> s.po;
 			if(s.po && (dps % PF_CH)) bad = true;
 			const uint32_t p = s.po ? i0 / dps : 0u;
-			if(s.type >= FA_SUB_FIXED) kk[sc] = w.winner[s.g].k[p];
+			if(s.type >= FA_SUB_FIXED) kk[sc] = w.winner[s.g].k[p << (kspread - s.po)];
 			int32_t xw[PF_W];
 #pragma unroll
 			for(int j = 0; j < PF_W; j++) {

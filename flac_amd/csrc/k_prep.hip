@@ -83,8 +83,130 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 	}
 }
 
+// ---- 16-bit stereo: one workgroup per FRAME, every signal of the frame from one read ------
+//
+// Each thread loads 16 wide samples (+4 of history) as packed dwords, forms left, right, mid
+// and side in registers and accumulates, per signal, the OR of the samples, "differs from
+// the first sample" and the five |k-th difference| sums.  Wasted bits are removed AFTER
+// summing: all samples of a signal share their trailing zeros, so the differences of the
+// shifted signal are the differences of the unshifted one shifted by the same amount
+// (nothing wraps below 28 bits), and sum >> wasted is exact.  The per-lane partials are
+// combined with a halving butterfly (each exchange step halves the number of values a lane
+// still carries: 31 shuffles for 20 sums instead of 120).
+#define PP_CH 16
+#define PP_HIST 4
+
+// Sum (or OR) NV = 2^m values across the 64 lanes of a wave; afterwards lane l holds the total
+// of value (l >> (6 - m)) in v[0].
+template<int NV, bool IS_OR>
+__device__ __forceinline__ void wave_combine(uint32_t (&v)[NV], uint32_t lane)
+{
+	int off = 32;
+#pragma unroll
+	for(int half = NV / 2; half >= 1; half >>= 1, off >>= 1) {
+		const bool hi = (lane & (uint32_t)off) != 0;
+#pragma unroll
+		for(int i = 0; i < half; i++) {
+			const uint32_t send = hi ? v[i] : v[i + half], keep = hi ? v[i + half] : v[i];
+			const uint32_t recv = (uint32_t)__shfl_xor((int)send, off, 64);
+			v[i] = IS_OR ? (keep | recv) : (keep + recv);
+		}
+	}
+#pragma unroll
+	for(; off >= 1; off >>= 1) { const uint32_t recv = (uint32_t)__shfl_xor((int)v[0], off, 64); v[0] = IS_OR ? (v[0] | recv) : (v[0] + recv); }
+}
+
+struct PrepFastShared { unsigned long long err[4][5]; uint32_t orv[4], ne[4]; };
+
+__global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
+{
+	__shared__ PrepFastShared sh;
+	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
+	const uint32_t i0 = tid * PP_CH;
+	if(tid < 20u) sh.err[tid / 5u][tid % 5u] = 0;
+	if(tid < 4u) { sh.orv[tid] = 0; sh.ne[tid] = 0; }
+
+	uint32_t raw[PP_HIST + PP_CH];
+#pragma unroll
+	for(int j = 0; j < (PP_HIST + PP_CH) / 4; j++) {
+		const int32_t rel = (int32_t)i0 - PP_HIST + 4 * j;
+		uint4 v = make_uint4(0u, 0u, 0u, 0u);
+		if(rel >= 0 && (uint32_t)rel + 4u <= n) v = *(const uint4*)(p + rel);
+		else if(rel >= 0 && (uint32_t)rel < n) { // tail of a short last block: never read past the end of the stream
+			v.x = p[rel];
+			if((uint32_t)rel + 1u < n) v.y = p[rel + 1];
+			if((uint32_t)rel + 2u < n) v.z = p[rel + 2];
+		}
+		raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
+	}
+	const uint32_t first = p[0];
+	__syncthreads();
+
+	uint32_t sums[4][5], orv[4], ne[4];
+#pragma unroll
+	for(int s = 0; s < 4; s++) {
+		const int32_t ca = (s == 1) ? 0 : 1, cb = (s == 0) ? 0 : (s == 3 ? -1 : 1);
+		const int sh1 = (s == 2) ? 1 : 0;
+		int32_t x[PP_HIST + PP_CH];
+#pragma unroll
+		for(int j = 0; j < PP_HIST + PP_CH; j++) {
+			const int32_t l = (int32_t)(int16_t)(raw[j] & 0xffffu), r = (int32_t)raw[j] >> 16;
+			x[j] = (ca * l + cb * r) >> sh1;
+		}
+		const int32_t x0 = (ca * (int32_t)(int16_t)(first & 0xffffu) + cb * ((int32_t)first >> 16)) >> sh1;
+		uint32_t o = 0, d = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+#pragma unroll
+		for(int q = 0; q < PP_CH; q++) {
+			const uint32_t i = i0 + (uint32_t)q;
+			if(i < n) {
+				const uint32_t a = (uint32_t)x[PP_HIST + q], b = (uint32_t)x[PP_HIST + q - 1], cc = (uint32_t)x[PP_HIST + q - 2], dd = (uint32_t)x[PP_HIST + q - 3], ee = (uint32_t)x[PP_HIST + q - 4];
+				o |= a; d |= (a != (uint32_t)x0) ? 1u : 0u;
+				if(i >= FA_MAX_FIXED_ORDER) { // fixed.c:229-243 sums start at the fifth sample
+					const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc), d3 = (int32_t)(a - 3u*b + 3u*cc - dd), d4 = (int32_t)(a - 4u*b + 6u*cc - 4u*dd + ee);
+					e0 += (uint32_t)(d0 < 0 ? -d0 : d0); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
+					e3 += (uint32_t)(d3 < 0 ? -d3 : d3); e4 += (uint32_t)(d4 < 0 ? -d4 : d4);
+				}
+			}
+		}
+		sums[s][0] = e0; sums[s][1] = e1; sums[s][2] = e2; sums[s][3] = e3; sums[s][4] = e4; orv[s] = o; ne[s] = d;
+	}
+
+	// ---- wave level: 16 + 4 sums and 4 + 4 OR values through halving butterflies
+	uint32_t va[16], vb[4], vo[8];
+#pragma unroll
+	for(int s = 0; s < 4; s++) {
+#pragma unroll
+		for(int k = 0; k < 4; k++) va[s * 4 + k] = sums[s][k];
+		vb[s] = sums[s][4]; vo[s] = orv[s]; vo[4 + s] = ne[s];
+	}
+	wave_combine<16, false>(va, lane);   // lane l: total of va[l >> 2]
+	wave_combine<4, false>(vb, lane);    // lane l: total of vb[l >> 4]
+	wave_combine<8, true>(vo, lane);     // lane l: OR of vo[l >> 3]
+	if((lane & 3u) == 0) { const uint32_t idx = lane >> 2; atomicAdd(&sh.err[idx >> 2][idx & 3u], (unsigned long long)va[0]); }
+	if((lane & 15u) == 0) atomicAdd(&sh.err[lane >> 4][4], (unsigned long long)vb[0]);
+	if((lane & 7u) == 0) { const uint32_t idx = lane >> 3; if(idx < 4u) atomicOr(&sh.orv[idx], vo[0]); else atomicOr(&sh.ne[idx - 4u], vo[0]); }
+	__syncthreads();
+
+	if(tid < c.nsig * 5u) {
+		const uint32_t s = tid / 5u, k = tid - s * 5u, g = f * c.nsig + s;
+		const uint32_t all = sh.orv[s];
+		const uint32_t wasted = all ? (uint32_t)__ffs((int)all) - 1u : 0u;
+		unsigned long long v = sh.err[s][k] >> wasted;
+		if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
+		w.fixed_err[(size_t)k * c.G + g] = v;
+		if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(sh.ne[s] ? 0 : 1); }
+	}
+}
+
 extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
+	// 16-bit stereo (left/right, plus mid/side when analysed) with blocks of at most 256 x 16 samples
+	if(c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && c->N <= 256u * PP_CH && (c->N % 4u) == 0 && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x2000u)) {
+		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
+		return;
+	}
 	const size_t lds = sizeof(int32_t) * (size_t)c->N;
 	hipLaunchKernelGGL(fa_prep_kernel, dim3(c->G), dim3(256), lds, st, pcm, *c, *w);
 }

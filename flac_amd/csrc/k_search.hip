@@ -38,12 +38,12 @@ struct SearchShared {
 };
 
 template<typename SUM>
-__global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
 
-	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
+	const uint32_t g = blockIdx.x + g0, f = g / c.nsig, s = g - f * c.nsig;   // g0: first signal of the range this launch covers
 	const uint32_t n = fa_frame_len(c, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;
@@ -285,8 +285,11 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 		const uint32_t bc = sh.best_cand;
 		const uint32_t hdr = w.cand_hdr[(size_t)bc * c.G + g];
 		const uint32_t order = FA_CAND_ORDER(hdr), po = sh.best_po;
+		// Rice parameters spread to the finest configured order: entry e belongs to partition e >> (emax - po),
+		// so that the pack stage can index them by sample position alone
+		const uint32_t emax = c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER;
 		bool big = false;
-		for(uint32_t p = tid; p < (1u << po); p += 256) { const uint8_t k = best_k[p]; win->k[p] = k; big |= (k >= 15); }
+		for(uint32_t pe = tid; pe < parts_cap; pe += 256) { const uint8_t k = best_k[pe >> (emax - po)]; win->k[pe] = k; big |= (k >= 15); }
 		if(big) atomicOr(&sh.rice2, 1u);
 		if(tid < FLACAMD_MAX_LPC_ORDER) win->q[tid] = (FA_CAND_KIND(hdr) && tid < order) ? w.cand_q[((size_t)bc * qrows + tid) * c.G + g] : 0;
 		__syncthreads();
@@ -320,15 +323,25 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 	return (b + 15u) & ~(size_t)15u;
 }
 
+extern "C" int fa_search_fast_ok(const FaCfg *c);
+extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, uint32_t frames, hipStream_t st);
+
 extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st)
 {
+	// full-length frames of common streams go to the register-resident kernel; a short last
+	// frame and everything else to the general one
+	uint32_t fast_frames = 0;
+	if(fa_search_fast_ok(c)) fast_frames = (c->last_n == c->N) ? c->F : c->F - 1u;
+	fa_launch_search_fast(pcm, c, w, cg, sum64, fast_frames, st);
+	const uint32_t g0 = fast_frames * c->nsig, rest = c->G - g0;
+	if(rest == 0) return;
 	const size_t lds = fa_search_lds_bytes(c, cg);
 	if(sum64) {
-		hipFuncSetAttribute((const void*)fa_search_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(fa_search_kernel<unsigned long long>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w, cg);
+		(void)hipFuncSetAttribute((const void*)fa_search_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_search_kernel<unsigned long long>, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
 	}
 	else {
-		hipFuncSetAttribute((const void*)fa_search_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(fa_search_kernel<uint32_t>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w, cg);
+		(void)hipFuncSetAttribute((const void*)fa_search_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_search_kernel<uint32_t>, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
 	}
 }

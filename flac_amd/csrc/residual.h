@@ -36,6 +36,88 @@ __device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)
 	return d;
 }
 
+// d = a.lo16 * b.lo16 + a.hi16 * b.hi16 + c (signed halves, 32-bit wrapping sum): two predictor
+// taps per instruction when samples and coefficients fit 16 bits
+__device__ __forceinline__ int32_t dot2_i16(uint32_t a, uint32_t b, int32_t c)
+{
+	int32_t d;
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+// d = |a - b| + c on unsigned operands
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+// (lo16 of lo) | (lo16 of hi) << 16
+__device__ __forceinline__ uint32_t pack_lo16(int32_t lo, int32_t hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+
+// f(s, x, pred, P): sample s of the chunk and its order-P prediction
+template<int P, int MODE, int W, class F>
+__device__ __forceinline__ void lpc_pred_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < W - HIST; s++) {
+		int32_t pred;
+		if(MODE == MAC_WIDE) {
+			long long acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+			pred = (int32_t)(acc >> shift);
+		}
+		else if(MODE == MAC_I24) {
+			int32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc = mad24(q[j], xw[HIST + s - 1 - j], acc);
+			pred = acc >> shift;
+		}
+		else {
+			uint32_t acc = 0;
+#pragma unroll
+			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
+			pred = (int32_t)acc >> shift;
+		}
+		f(s, xw[HIST + s], pred, P);
+	}
+}
+
+// the same on packed pairs: xp[t] = pack_lo16(xw[t], xw[t-1]), qp[m] = pack_lo16(q[2m], q[2m+1]);
+// exact (mod 2^32, like the 32-bit path of lpc.c:296) when samples and coefficients fit 16 bits
+template<int P, int W, class F>
+__device__ __forceinline__ void lpc_pred_each_dot2(const int32_t (&xw)[W], const uint32_t (&xp)[W], const uint32_t (&qp)[HIST / 2], uint32_t shift, F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < W - HIST; s++) {
+		int32_t acc = 0;
+#pragma unroll
+		for(int m = 0; m < (P + 1) / 2; m++) acc = dot2_i16(qp[m], xp[HIST + s - 1 - 2 * m], acc);
+		f(s, xw[HIST + s], acc >> shift, P);
+	}
+}
+
+#define RESIDUAL_ORDER_SWITCH(order, CALL) \
+	switch(order) { \
+	case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+	case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; \
+	case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; default: CALL(12); break; }
+
+template<int MODE, int W, class F>
+__device__ __forceinline__ void lpc_pred_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+#define RESIDUAL_CALL(P) lpc_pred_each<P, MODE>(xw, q, shift, f)
+	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
+#undef RESIDUAL_CALL
+}
+template<int W, class F>
+__device__ __forceinline__ void lpc_pred_each_dot2_dispatch(uint32_t order, const int32_t (&xw)[W], const uint32_t (&xp)[W], const uint32_t (&qp)[HIST / 2], uint32_t shift, F &&f)
+{
+#define RESIDUAL_CALL(P) lpc_pred_each_dot2<P>(xw, xp, qp, shift, f)
+	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
+#undef RESIDUAL_CALL
+}
+
 // f(s, r, P): residual r of chunk sample s under an order-P predictor
 template<int P, int MODE, int W, class F>
 __device__ __forceinline__ void lpc_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
