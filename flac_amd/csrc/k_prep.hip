@@ -10,6 +10,7 @@
 // from LDS with unit stride.  HBM traffic: the frame's PCM once per signal (L2 absorbs the
 // repeats), a few dozen bytes out.
 #include "engine_types.h"
+#include "wave_ops.h"
 
 __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 {
@@ -95,26 +96,6 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 // still carries: 31 shuffles for 20 sums instead of 120).
 #define PP_CH 16
 #define PP_HIST 4
-
-// Sum (or OR) NV = 2^m values across the 64 lanes of a wave; afterwards lane l holds the total
-// of value (l >> (6 - m)) in v[0].
-template<int NV, bool IS_OR>
-__device__ __forceinline__ void wave_combine(uint32_t (&v)[NV], uint32_t lane)
-{
-	int off = 32;
-#pragma unroll
-	for(int half = NV / 2; half >= 1; half >>= 1, off >>= 1) {
-		const bool hi = (lane & (uint32_t)off) != 0;
-#pragma unroll
-		for(int i = 0; i < half; i++) {
-			const uint32_t send = hi ? v[i] : v[i + half], keep = hi ? v[i + half] : v[i];
-			const uint32_t recv = (uint32_t)__shfl_xor((int)send, off, 64);
-			v[i] = IS_OR ? (keep | recv) : (keep + recv);
-		}
-	}
-#pragma unroll
-	for(; off >= 1; off >>= 1) { const uint32_t recv = (uint32_t)__shfl_xor((int)v[0], off, 64); v[0] = IS_OR ? (v[0] | recv) : (v[0] + recv); }
-}
 
 struct PrepFastShared { unsigned long long err[4][5]; uint32_t orv[4], ne[4]; };
 

@@ -2,21 +2,36 @@
 // replaced in the reference and for the general kernel).
 //
 // Applies to full-length blocks of at most 4096 samples whose finest partitions are whole
-// multiples of 8 samples and to predictor orders up to HIST: the common streams.  One
-// 512-thread workgroup per (frame, signal), 8 samples + HIST of history per thread, read
-// straight from the interleaved PCM into registers (left/right/mid/side are formed from the
-// same words): no LDS copy of the signal, so the workgroup's LDS holds only the partition
-// sums and the small candidate table, and twice as many waves per SIMD stay resident to
-// hide the load and barrier latencies around the multiply-add phase.  Every global load
-// the workgroup needs is issued before the first barrier.  After the Rice evaluation the
-// first wave alone finishes the job with shuffles (best partition order per candidate,
-// ordered arg-min over candidates, winner record), so no further barriers are needed.
+// multiples of 8 samples, to partition orders up to 6 and predictor orders up to HIST: the
+// common streams.  One 512-thread workgroup per (frame, signal), 8 samples + HIST of history
+// per thread, read straight from the interleaved PCM into registers (left/right/mid/side are
+// formed from the same words): no LDS copy of the signal.  Every global load the workgroup
+// needs is issued before the first barrier.
+//
+//   multiply-add phase  every thread evaluates all candidates on its 8 samples; 16-bit signals
+//                       take two taps per instruction (v_dot2_i32_i16 on packed pairs) and
+//                       |x - pred| accumulates in one instruction (v_sad_u32); one LDS atomic per
+//                       thread and candidate into the 64 finest-partition sums
+//   evaluation phase    one WAVE per candidate, no barriers and no atomics: lane p holds the sum
+//                       of finest partition p, six shuffle-add steps build the sums of every
+//                       coarser partition order in place, every lane prices the partitions it
+//                       owns (Rice parameter, bits), a halving butterfly totals the bits per
+//                       order, the best order is chosen and its parameters parked in LDS
+//   first wave          ordered arg-min over the candidates (estimate, then index: the
+//                       reference's strict-'<' keep-first rule) and the winner record
+//
+// Three barriers per workgroup.
 #include "engine_types.h"
 #include "residual.h"
+#include "wave_ops.h"
 
 #define SF_THREADS 512
 #define SF_CH 8
 #define SF_W (HIST + SF_CH)
+#define SF_WAVES (SF_THREADS / 64)
+#define SF_PARTS 64u     // finest partitions one wave prices: partition orders up to 6
+#define SF_LEVELS 7
+#define SF_ROW 128u      // entries of a candidate's row of partition sums: all orders, finest first
 
 __device__ __forceinline__ uint32_t sf_limit_po(uint32_t limit, uint32_t blocksize, uint32_t order) // format.c:548-561
 {
@@ -24,8 +39,37 @@ __device__ __forceinline__ uint32_t sf_limit_po(uint32_t limit, uint32_t blocksi
 	return limit;
 }
 
-// PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample
-template<typename SUM, int PK>
+// Rice parameter of a partition of nsamp residuals with |residual| sum `sum` (stream_encoder.c:4052:
+// the smallest k with nsamp << k >= sum, clipped) and the bits it costs (:3929-3937, unsigned 32-bit)
+template<typename SUM>
+__device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given_k, uint32_t given_k, uint32_t k_limit, uint32_t &k, uint32_t &est)
+{
+	if(sizeof(SUM) == 4) {
+		const uint32_t s32 = (uint32_t)sum;
+		k = s32 > nsamp ? (uint32_t)__clz((int)nsamp) - (uint32_t)__clz((int)s32) : 0u;   // nsamp << k now has the bit length of sum
+		k += ((nsamp << k) < s32) ? 1u : 0u;
+		if(k >= k_limit) k = k_limit - 1u;
+		if(use_given_k) k = given_k;
+		est = 4u + (1u + k) * nsamp + (k ? (s32 >> (k - 1u)) : (s32 << 1)) - (nsamp >> 1);
+	}
+	else {
+		const unsigned long long s64 = (unsigned long long)sum;
+		k = 0;
+		if(s64 > (unsigned long long)nsamp) {
+			const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)s64), bl_n = 32u - (uint32_t)__clz((int)nsamp);
+			k = bl_s - bl_n;
+			if(((unsigned long long)nsamp << k) < s64) k++;
+		}
+		if(k >= k_limit) k = k_limit - 1u;
+		if(use_given_k) k = given_k;
+		est = 4u + (1u + k) * nsamp + (k ? (uint32_t)(s64 >> (k - 1u)) : (uint32_t)(s64 << 1)) - (nsamp >> 1);
+	}
+}
+
+// PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample.
+// LIGHT = 1: no candidate of the stream can need the 64-bit prediction sum or more than 24-bit
+// samples (decided on the host), so those paths and their registers are compiled out.
+template<typename SUM, int PK, int LIGHT>
 __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -33,7 +77,7 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
 	const uint32_t n = c.N;
 	const uint64_t base = (uint64_t)f * c.N;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t i0 = tid * SF_CH;
 	const uint32_t wasted = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.wasted[g]);
 	const uint32_t ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ncand[g]);
@@ -42,20 +86,21 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 
 	// frame-level partition order range (stream_encoder.c:2934-2941); every block here is full length
 	const uint32_t tz = (uint32_t)__ffs((int)n) - 1u;
-	const uint32_t maxpo_f = tz < c.max_po ? tz : c.max_po;
+	const uint32_t maxpo_f = tz < c.max_po ? tz : c.max_po;            // <= 6 (host check)
 	const uint32_t minpo_f = c.min_po < maxpo_f ? c.min_po : maxpo_f;
 	const uint32_t parts0 = 1u << maxpo_f, dps0 = n >> maxpo_f;
 	const uint32_t emax = c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER;
-	const uint32_t parts_cap = 1u << emax, prow = 2u * parts_cap;
+	const uint32_t parts_cap = 1u << emax;
 
 	// LDS carve-up
 	int32_t *cq = (int32_t*)lds_raw;                                   // [cg][HIST] coefficients
-	SUM *psum = (SUM*)(cq + (size_t)cg * HIST);                        // [cg][prow] |residual| sums: finest order first, then each coarser one
-	uint32_t *lbits = (uint32_t*)(psum + (size_t)cg * prow);           // [cg][16] bits per partition order
-	uint32_t *chdr = lbits + (size_t)cg * 16u;                         // [cg] candidate headers
+	SUM *psum = (SUM*)(cq + (size_t)cg * HIST);                        // [cg][128] |residual| sums of the partitions of every order
+	unsigned long long *ckey = (unsigned long long*)(psum + (size_t)cg * SF_ROW);   // [cg] (estimate << 32) | candidate index
+	uint32_t *cqp = (uint32_t*)(ckey + cg);                            // [cg][HIST/2] coefficient pairs for the two-tap instruction
+	uint32_t *chdr = cqp + (size_t)cg * (HIST / 2);                    // [cg] candidate headers
 	uint32_t *cinfo = chdr + cg;                                       // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
-	uint32_t *cqp = cinfo + cg;                                        // [cg][HIST/2] coefficient pairs for the two-tap instruction
-	uint8_t *kbuf = (uint8_t*)(cqp + (size_t)cg * (HIST / 2));         // [cg][prow] Rice parameters
+	uint32_t *cpo = cinfo + cg;                                        // [cg] best partition order | rice2 << 8
+	uint8_t *kbuf = (uint8_t*)(cpo + cg);                              // [cg][64] Rice parameters at the candidate's best order
 
 	// ---- this thread's samples i0 - HIST .. i0 + SF_CH - 1, issued before anything waits
 	int32_t xw[SF_W];
@@ -86,17 +131,14 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 		}
 	}
 
-	// thread-level partial sums: 32 bits where the reference's own accumulators are 32 bits
-	typedef SUM PART;
+	// samples biased into unsigned order for the |a - b| instruction
+	uint32_t xb[SF_CH];
+#pragma unroll
+	for(int j = 0; j < SF_CH; j++) xb[j] = (uint32_t)xw[HIST + j] ^ 0x80000000u;
 	// samples and coefficients fit 16 bits: two taps per instruction (the side channel of a
 	// 16-bit stream has 17 bits and stays on the one-tap path)
 	const bool use_dot2 = bps <= 16u && !(c.debug & 0x8000u);
-	uint32_t xp[SF_W], xb[SF_CH];
-	xp[0] = 0;
-#pragma unroll
-	for(int j = 1; j < SF_W; j++) xp[j] = pack_lo16(xw[j], xw[j - 1]);
-#pragma unroll
-	for(int j = 0; j < SF_CH; j++) xb[j] = (uint32_t)xw[HIST + j] ^ 0x80000000u;
+	const bool sad_on = sizeof(SUM) == 4 && !(c.debug & 0x4000u);
 
 	const uint32_t qrows = c.max_lpc_order ? c.max_lpc_order : 1u;
 	const uint32_t part = i0 / dps0;
@@ -111,8 +153,7 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 
 	for(uint32_t cb = 0; cb < ncand; cb += cg) {
 		const uint32_t gn = (ncand - cb) < cg ? (ncand - cb) : cg;
-		for(uint32_t t = tid; t < gn * parts0; t += SF_THREADS) psum[(size_t)(t / parts0) * prow + (t % parts0)] = 0;
-		for(uint32_t t = tid; t < gn * 16u; t += SF_THREADS) lbits[t] = 0;
+		for(uint32_t t = tid; t < cg * SF_ROW; t += SF_THREADS) psum[t] = 0;
 		// candidate headers and coefficients of this group: one parallel fetch into LDS, for every
 		// slot of the group whether used or not, so that the loads do not wait for the candidate count
 		for(uint32_t t = tid; t < cg * (HIST / 2 + 1u); t += SF_THREADS) {
@@ -146,174 +187,150 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 		// sample of the chunk goes (statically) to one of three accumulators, of which thread 0 keeps
 		// only the tail, thread 1 the tail and the head, every other thread all three.
 		if(active && !(c.debug & 1u)) {
-			for(uint32_t ci = 0; ci < gn; ci++) {
-				const uint32_t hdr = chdr[ci];
-				const uint32_t order = FA_CAND_ORDER(hdr);
-				PART accT = 0, accH = 0, accM = 0;
-				auto by_residual = [&](int sidx, int32_t rv, int P) {
-					const uint32_t m = abs_u32(rv);
-					if(sidx + SF_CH < P) accM += m; else if(sidx < P) accH += m; else accT += m;
-				};
-				auto by_abs = [&](int sidx, int32_t x, int32_t pred, int P) { by_residual(sidx, (int32_t)((uint32_t)x - (uint32_t)pred), P); };
-				// |x - pred| + acc in one instruction on operands biased into unsigned order; equals the
-				// reference's abs(x - pred) whenever x - pred does not wrap, which |pred| <= 2^30 (shift >= 1) ensures
-				auto by_sad = [&](int sidx, int32_t, int32_t pred, int P) {
-					const uint32_t pb = (uint32_t)pred ^ 0x80000000u;
-					if(sidx + SF_CH < P) accM = (PART)sad_u32(xb[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (PART)sad_u32(xb[sidx], pb, (uint32_t)accH); else accT = (PART)sad_u32(xb[sidx], pb, (uint32_t)accT);
-				};
-				if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, by_residual);
-				else {
-					const uint32_t shift = FA_CAND_SHIFT(hdr);
-					const bool sad_ok = sizeof(SUM) == 4 && shift >= 1u && bps <= 24u && !(c.debug & 0x4000u);
-					if(FA_CAND_WIDE(hdr) || !sad_ok) {
-						int32_t q[HIST];
-						const int4 *q4 = (const int4*)(cq + ci * HIST);
-						const int4 qa = q4[0], qb = q4[1], qc = q4[2];
-						q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w; q[8] = qc.x; q[9] = qc.y; q[10] = qc.z; q[11] = qc.w;
-						if(FA_CAND_WIDE(hdr)) lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs);
-						else lpc_pred_each_dispatch<MAC_I32>(order, xw, q, shift, by_abs);
-					}
-					else if(use_dot2) {
+			SUM accT, accH, accM;
+			auto by_residual = [&](int sidx, int32_t rv, int P) {
+				const uint32_t m = abs_u32(rv);
+				if(sidx + SF_CH < P) accM += m; else if(sidx < P) accH += m; else accT += m;
+			};
+			auto by_abs = [&](int sidx, int32_t x, int32_t pred, int P) { by_residual(sidx, (int32_t)((uint32_t)x - (uint32_t)pred), P); };
+			// |x - pred| + acc in one instruction on operands biased into unsigned order; equals the
+			// reference's abs(x - pred) whenever x - pred does not wrap, which |pred| <= 2^30 (shift >= 1) ensures
+			auto by_sad = [&](int sidx, int32_t, int32_t pred, int P) {
+				const uint32_t pb = (uint32_t)pred ^ 0x80000000u;
+				if(sidx + SF_CH < P) accM = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accH); else accT = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accT);
+			};
+			auto deposit = [&](uint32_t ci) {
+				const SUM v = accT + (tid >= 1u ? accH : (SUM)0) + (tid >= 2u ? accM : (SUM)0);
+				atomicAdd(&psum[(size_t)ci * SF_ROW + part], v);
+			};
+#define SF_LOAD_Q(ci, q) do { \
+				const int4 *q4_ = (const int4*)(cq + (ci) * HIST); \
+				const int4 qa_ = q4_[0], qb_ = q4_[1], qc_ = q4_[2]; \
+				q[0] = qa_.x; q[1] = qa_.y; q[2] = qa_.z; q[3] = qa_.w; q[4] = qb_.x; q[5] = qb_.y; q[6] = qb_.z; q[7] = qb_.w; q[8] = qc_.x; q[9] = qc_.y; q[10] = qc_.z; q[11] = qc_.w; } while(0)
+			if(use_dot2) {
+				// packed pairs xp[t] = (x[t], x[t-1]); the unpacked history is dead from here on
+				uint32_t xp[SF_W];
+				xp[0] = 0;
+#pragma unroll
+				for(int j = 1; j < SF_W; j++) xp[j] = pack_lo16(xw[j], xw[j - 1]);
+				for(uint32_t ci = 0; ci < gn; ci++) {
+					const uint32_t hdr = chdr[ci];
+					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
+					accT = 0; accH = 0; accM = 0;
+					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, by_residual);
+					else if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
+					else {
 						uint32_t qp[HIST / 2];
 						const uint2 *q2 = (const uint2*)(cqp + ci * (HIST / 2));
 						const uint2 pa = q2[0], pb = q2[1], pc = q2[2];
 						qp[0] = pa.x; qp[1] = pa.y; qp[2] = pb.x; qp[3] = pb.y; qp[4] = pc.x; qp[5] = pc.y;
-						lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_sad);
+						if(sad_on && shift >= 1u) lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_sad);
+						else lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_abs);
 					}
+					deposit(ci);
+				}
+			}
+			else {
+				for(uint32_t ci = 0; ci < gn; ci++) {
+					const uint32_t hdr = chdr[ci];
+					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
+					accT = 0; accH = 0; accM = 0;
+					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, by_residual);
 					else {
 						int32_t q[HIST];
-						const int4 *q4 = (const int4*)(cq + ci * HIST);
-						const int4 qa = q4[0], qb = q4[1], qc = q4[2];
-						q[0] = qa.x; q[1] = qa.y; q[2] = qa.z; q[3] = qa.w; q[4] = qb.x; q[5] = qb.y; q[6] = qb.z; q[7] = qb.w; q[8] = qc.x; q[9] = qc.y; q[10] = qc.z; q[11] = qc.w;
-						lpc_pred_each_dispatch<MAC_I24>(order, xw, q, shift, by_sad);
+						SF_LOAD_Q(ci, q);
+						if(!LIGHT && FA_CAND_WIDE(hdr)) lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs);
+						else if(!LIGHT && bps > 24u) lpc_pred_each_dispatch<MAC_I32>(order, xw, q, shift, by_abs);
+						else if(sad_on && shift >= 1u) lpc_pred_each_dispatch<MAC_I24>(order, xw, q, shift, by_sad);
+						else lpc_pred_each_dispatch<MAC_I24>(order, xw, q, shift, by_abs);
 					}
+					deposit(ci);
 				}
-				const SUM v = (SUM)accT + (tid >= 1u ? (SUM)accH : (SUM)0) + (tid >= 2u ? (SUM)accM : (SUM)0);
-				atomicAdd(&psum[(size_t)ci * prow + part], v);
 			}
 		}
+#undef SF_LOAD_Q
 		SF_STAMP(2);
 		__syncthreads();
 		SF_STAMP(3);
 
-		// ---- sums of the coarser partition orders: pairwise merges, three orders per barrier.
-		// A value read at the candidate's own finest order is first wrapped to 32 bits when the
-		// reference's accumulator there is 32 bits wide.
-		for(uint32_t l0 = 0; l0 < maxpo_f; l0 += 3) {
-			const uint32_t lto = (l0 + 3u < maxpo_f) ? l0 + 3u : maxpo_f, span = lto - l0;
-			const uint32_t cnt_to = parts0 >> lto, fan = 1u << span;
-			for(uint32_t t = tid; t < gn * cnt_to; t += SF_THREADS) {
-				const uint32_t ci = t / cnt_to, pg = t - ci * cnt_to;
-				const uint32_t info = cinfo[ci];
-				const uint32_t lvl_c = maxpo_f - ((info >> 8) & 15u);
-				const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
-				SUM *row = psum + (size_t)ci * prow;
-				SUM v[8];
-				const uint32_t off0 = 2u * parts0 - ((2u * parts0) >> l0);
-#pragma unroll
-				for(uint32_t i = 0; i < 8; i++) if(i < fan) { v[i] = row[off0 + pg * fan + i]; if(narrow_c && l0 == lvl_c) v[i] &= (SUM)0xffffffffull; }
-				uint32_t width = fan;
-#pragma unroll
-				for(uint32_t d = 1; d <= 3; d++) if(d <= span) {
-					width >>= 1;
-					const uint32_t lv = l0 + d, off = 2u * parts0 - ((2u * parts0) >> lv);
-#pragma unroll
-					for(uint32_t i = 0; i < 4; i++) if(i < width) {
-						SUM m = v[2*i] + v[2*i+1];
-						row[off + pg * width + i] = m;
-						if(narrow_c && lv == lvl_c) m &= (SUM)0xffffffffull;
-						v[i] = m;
-					}
-				}
-			}
-			__syncthreads();
-		}
-
-		SF_STAMP(4);
-		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition)
+		// ---- one wave per candidate: sums of every partition order by in-register doubling steps,
+		// then every lane prices two partitions (its finest one, and one of the 2^maxpo - 1 coarser
+		// ones, fetched through the candidate's LDS row), bits per order, best order (searched
+		// max -> min, strict '<'), subframe estimate
 		const uint32_t per = 2u * parts0, per_log = maxpo_f + 1u;
-		for(uint32_t t = tid; t < ((c.debug & 2u) ? 0u : gn * per); t += SF_THREADS) {
-			const uint32_t ci = t >> per_log, idx = t & (per - 1u);
-			if(idx == per - 1u) continue;
-			// idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
-			const uint32_t lvl = per_log - (32u - (uint32_t)__clz((int)(per - idx - 1u)));
-			const uint32_t off = per - (per >> lvl);
-			const uint32_t po = maxpo_f - lvl, p = idx - off;
-			const uint32_t info = cinfo[ci];
+		for(uint32_t ci = wave; ci < ((c.debug & 2u) ? 0u : gn); ci += SF_WAVES) {
+			const uint32_t hdr = chdr[ci], info = cinfo[ci];
 			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
-			if(po > maxpo_c || po < minpo_c) continue;
-			const uint32_t nsamp = (n >> po) - (p == 0 ? order : 0u);
-			uint32_t k, est;
-			if(sizeof(SUM) == 4) {
-				const uint32_t sum = (uint32_t)psum[(size_t)ci * prow + idx];
-				if(po == 0) k = FA_CAND_K(chdr[ci]);   // stream_encoder.c:3982-4029
-				else {                                  // :4052 smallest k with nsamp << k >= sum
-					k = 0;
-					if(sum > nsamp) {
-						k = (uint32_t)__clz((int)nsamp) - (uint32_t)__clz((int)sum);   // nsamp << k has the bit length of sum
-						if((nsamp << k) < sum) k++;
+			const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
+			const uint32_t lvl_c = maxpo_f - maxpo_c;
+			SUM *row = psum + (size_t)ci * SF_ROW;
+			SUM vA = (lane < parts0) ? row[lane] : (SUM)0;
+			// a value at the candidate's own finest order is wrapped to 32 bits when the reference's
+			// accumulator there is 32 bits wide; coarser orders add the wrapped values
+			if(narrow_c && lvl_c == 0u) vA &= (SUM)0xffffffffull;
+			SUM v = vA;
+#pragma unroll
+			for(int l = 1; l < SF_LEVELS; l++) {
+				if((uint32_t)l <= maxpo_f) {
+					switch(l) {
+					case 1: v = block_sum_step<1>(v); break; case 2: v = block_sum_step<2>(v); break; case 3: v = block_sum_step<3>(v); break;
+					case 4: v = block_sum_step<4>(v); break; case 5: v = block_sum_step<5>(v); break; default: v = block_sum_step<6>(v); break;
 					}
-					if(k >= c.k_limit) k = c.k_limit - 1u;
+					if(narrow_c && (uint32_t)l == lvl_c) v &= (SUM)0xffffffffull;
+					// the first lane of every aligned block of 2^l files the block's sum: orders are laid out
+					// finest first (parts0 entries), then parts0/2, ... as in the general kernel
+					if((lane & ((1u << l) - 1u)) == 0 && lane < parts0) row[per - (per >> l) + (lane >> l)] = v;
 				}
-				// :3929-3937, unsigned 32-bit arithmetic
-				est = 4u + (1u + k) * nsamp + (k ? (sum >> (k - 1u)) : (sum << 1)) - (nsamp >> 1);
 			}
-			else {
-				unsigned long long sum = psum[(size_t)ci * prow + idx];
-				if(((info >> 16) & 1u) && po == maxpo_c) sum &= 0xffffffffull;
-				if(po == 0) k = FA_CAND_K(chdr[ci]);
-				else {
-					k = 0;
-					if(sum > (unsigned long long)nsamp) {
-						const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)sum), bl_n = 32u - (uint32_t)__clz((int)nsamp);
-						k = bl_s - bl_n;
-						if(((unsigned long long)nsamp << k) < sum) k++;
-					}
-					if(k >= c.k_limit) k = c.k_limit - 1u;
-				}
-				est = 4u + (1u + k) * nsamp + (k ? (uint32_t)(sum >> (k - 1u)) : (uint32_t)(sum << 1)) - (nsamp >> 1);
+			// second item of this lane: entry parts0 + lane of the row (the last lane has none)
+			const uint32_t idxB = parts0 + lane;
+			const bool hasB = lane + 1u < parts0;
+			const SUM vB = hasB ? row[idxB] : (SUM)0;
+			const uint32_t lB = hasB ? per_log - (32u - (uint32_t)__clz((int)(per - idxB - 1u))) : 7u;
+			const uint32_t pB = idxB - (per - (per >> lB));
+			const uint32_t poA = maxpo_f, poB = maxpo_f - (lB < 7u ? lB : 0u);
+			uint32_t kA, estA, kB, estB;
+			sf_price<SUM>(vA, (n >> poA) - (lane == 0 ? order : 0u), poA == 0, FA_CAND_K(hdr), c.k_limit, kA, estA);   // order 0 takes the suggested parameter, stream_encoder.c:3982-4029
+			sf_price<SUM>(vB, (n >> poB) - (pB == 0 ? order : 0u), poB == 0, FA_CAND_K(hdr), c.k_limit, kB, estB);
+			if(!(lane < parts0 && poA <= maxpo_c && poA >= minpo_c)) estA = 0;
+			if(!(hasB && poB <= maxpo_c && poB >= minpo_c)) estB = 0;
+			uint32_t tot[8];
+#pragma unroll
+			for(int j = 0; j < 8; j++) tot[j] = (j == 0 ? estA : 0u) + (lB == (uint32_t)j ? estB : 0u);
+			wave_combine<8, false>(tot, lane);   // lane l: bits of level l >> 3
+			uint32_t best = 0, bestpo = 0; bool have = false;
+			for(int po = (int)maxpo_c; po >= (int)minpo_c; po--) {
+				const uint32_t b = 6u + (uint32_t)__builtin_amdgcn_readlane((int)tot[0], (int)((maxpo_f - (uint32_t)po) * 8u));
+				if(!have || b < best) { best = b; bestpo = (uint32_t)po; have = true; }
 			}
-			kbuf[(size_t)ci * prow + idx] = (uint8_t)k;
-			atomicAdd(&lbits[ci * 16u + lvl], est);
+			uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
+			if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
+			// park the parameters of the best order: entry p of the row is partition p
+			const uint32_t bl = maxpo_f - bestpo;
+			const bool own_b = bl == 0u ? (lane < parts0) : (hasB && lB == bl);
+			const uint32_t kb = bl == 0u ? kA : kB;
+			if(own_b) kbuf[(size_t)ci * SF_PARTS + (bl == 0u ? lane : pB)] = (uint8_t)kb;
+			const uint32_t big = __any((own_b && kb >= 15u) ? 1 : 0) ? 1u : 0u;
+			if(lane == 0) { ckey[ci] = ((unsigned long long)est << 32) | (unsigned long long)(cb + ci); cpo[ci] = bestpo | (big << 8); }
 		}
+		SF_STAMP(4);
 		__syncthreads();
-
 		SF_STAMP(5);
-		// ---- first wave: best partition order of each candidate (searched max -> min, strict '<'),
-		// subframe estimate, ordered arg-min over the group (estimate, then candidate index)
-		if(tid < 64u) {
-			unsigned long long key = ~0ull; uint32_t mypo = 0;
-			if(lane < gn) {
-				const uint32_t hdr = chdr[lane], info = cinfo[lane];
-				const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
-				uint32_t best = 0; bool have = false;
-				for(int po = (int)maxpo_c; po >= (int)minpo_c; po--) {
-					const uint32_t b = 6u + lbits[lane * 16u + (maxpo_f - (uint32_t)po)];
-					if(!have || b < best) { best = b; mypo = (uint32_t)po; have = true; }
-				}
-				uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
-				if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
-				key = ((unsigned long long)est << 32) | (unsigned long long)(cb + lane);
-			}
-			unsigned long long bk = key;
+
+		// ---- first wave: ordered arg-min over the group (estimate, then candidate index)
+		if(tid < 64u && !(c.debug & 2u)) {
+			unsigned long long bk = (lane < gn) ? ckey[lane] : ~0ull;
 #pragma unroll
 			for(int o = 32; o > 0; o >>= 1) { const unsigned long long t = (unsigned long long)__shfl_xor((long long)bk, o, 64); bk = t < bk ? t : bk; }
 			const uint32_t est = (uint32_t)(bk >> 32), widx = (uint32_t)bk - cb;
-			const uint32_t po_w = (uint32_t)__shfl((int)mypo, (int)widx, 64);
 			// earlier groups hold earlier candidates: replace only when strictly smaller
 			if(!have_best || est < best_est) {
-				have_best = 1; best_est = est; best_cand = cb + widx; best_po = po_w;
+				const uint32_t pw = cpo[widx];
+				have_best = 1; best_est = est; best_cand = cb + widx; best_po = pw & 255u; best_rice2 = pw >> 8;
 				best_hdr = chdr[widx]; best_q = (lane < (uint32_t)HIST) ? cq[widx * HIST + lane] : 0;
 				// Rice parameters of the winner, spread to the finest configured order so that the
 				// pack stage can index them by sample position alone
-				const uint32_t lvl = maxpo_f - po_w;
-				const uint32_t off = per - (per >> lvl);
-				bool big = false;
-				for(uint32_t pe = lane; pe < parts_cap; pe += 64u) {
-					const uint8_t k = kbuf[(size_t)widx * prow + off + (pe >> (emax - po_w))];
-					win->k[pe] = k; big |= (k >= 15);
-				}
-				best_rice2 = __any(big ? 1 : 0) ? 1u : 0u;
+				for(uint32_t pe = lane; pe < parts_cap; pe += 64u) win->k[pe] = kbuf[(size_t)widx * SF_PARTS + (pe >> (emax - best_po))];
 			}
 		}
 		if(cb + cg < ncand) __syncthreads();
@@ -351,26 +368,25 @@ __global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *
 
 extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum64)
 {
-	const size_t emax = c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER;
-	const size_t prow = (size_t)2 << emax;
+	(void)c;
 	size_t b = (size_t)cg * HIST * 4u;               // cq
-	b += (size_t)cg * prow * (sum64 ? 8u : 4u);      // psum
-	b += (size_t)cg * 16u * 4u;                      // lbits
-	b += (size_t)cg * 4u * 2u;                       // chdr, cinfo
+	b += (size_t)cg * SF_ROW * (sum64 ? 8u : 4u);    // psum
+	b += (size_t)cg * 8u;                            // ckey
 	b += (size_t)cg * (HIST / 2) * 4u;               // cqp
-	b += (size_t)cg * prow;                          // kbuf
+	b += (size_t)cg * 4u * 3u;                       // chdr, cinfo, cpo
+	b += (size_t)cg * SF_PARTS;                      // kbuf
 	return (b + 15u) & ~(size_t)15u;
 }
 
 // Full-length blocks that fit 512 x 8 samples, with finest partitions that are multiples of
-// 8 samples and predictor orders within the register window.
+// 8 samples, at most 64 of them, and predictor orders within the register window.
 extern "C" int fa_search_fast_ok(const FaCfg *c)
 {
 	if(c->N > (uint32_t)(SF_THREADS * SF_CH) || (c->N % SF_CH) != 0 || c->max_lpc_order > (uint32_t)HIST || (c->debug & 0x800u)) return 0;
 	uint32_t tz = 0;
 	while(!((c->N >> tz) & 1u)) tz++;
 	const uint32_t maxpo = tz < c->max_po ? tz : c->max_po;
-	return ((c->N >> maxpo) % SF_CH) == 0;
+	return maxpo <= 6u && ((c->N >> maxpo) % SF_CH) == 0;
 }
 
 // `frames` full-length frames starting at frame 0 of the batch
@@ -380,10 +396,18 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 	const size_t lds = fa_search_fast_lds_bytes(c, cg, sum64);
 	const dim3 grid(frames * c->nsig), block(SF_THREADS);
 	const bool pk = c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && ((uintptr_t)pcm % 16u) == 0;
-#define SF_LAUNCH(SUMT, PKV) do { \
-		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
-	if(sum64) { if(pk) SF_LAUNCH(unsigned long long, 1); else SF_LAUNCH(unsigned long long, 0); }
-	else { if(pk) SF_LAUNCH(uint32_t, 1); else SF_LAUNCH(uint32_t, 0); }
+	// can any candidate take the 64-bit prediction sum (stream_encoder.c:3597-3603: bps + precision + ilog2(order) > 32)
+	// or carry more than 24-bit samples?
+	uint32_t lg = 0;
+	while((2u << lg) <= (c->max_lpc_order ? c->max_lpc_order : 1u)) lg++;
+	const uint32_t max_prec = c->prec_search ? FA_MAX_QLP_PRECISION : c->qlp_precision;
+	const uint32_t max_bps = c->bps + (c->midside ? 1u : 0u);
+	const bool light = !sum64 && max_bps <= 24u && max_bps + max_prec + lg <= 32u;
+#define SF_LAUNCH(SUMT, PKV, LV) do { \
+		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV, LV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
+	if(sum64) { if(pk) SF_LAUNCH(unsigned long long, 1, 0); else SF_LAUNCH(unsigned long long, 0, 0); }
+	else if(light) { if(pk) SF_LAUNCH(uint32_t, 1, 1); else SF_LAUNCH(uint32_t, 0, 1); }
+	else { if(pk) SF_LAUNCH(uint32_t, 1, 0); else SF_LAUNCH(uint32_t, 0, 0); }
 #undef SF_LAUNCH
 }
