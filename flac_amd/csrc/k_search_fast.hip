@@ -69,8 +69,10 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 // PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample.
 // LIGHT = 1: no candidate of the stream can need the 64-bit prediction sum or more than 24-bit
 // samples (decided on the host), so those paths and their registers are compiled out.
+// Capped at 80 registers (6 waves per SIMD: three workgroups per CU): the few spills cost less
+// than the third workgroup gains in hiding the load and evaluation latencies (measured).
 template<typename SUM, int PK, int LIGHT>
-__global__ void __launch_bounds__(SF_THREADS) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 
