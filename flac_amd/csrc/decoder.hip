@@ -445,6 +445,7 @@ struct flacamd_decoder {
 	void *arena; size_t arena_bytes;
 	size_t max_bytes;
 	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
+	uint32_t last_ncand, last_nframes;
 };
 
 #define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
@@ -520,6 +521,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	uint32_t ncand = 0;
 	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
 	FD_TRY(hipStreamSynchronize(st));
+	d->last_ncand = 0; d->last_nframes = 0;
 	if(ncand == 0) return FLACAMD_E_BAD_STREAM;
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
 	hipLaunchKernelGGL(fd_decode_kernel, dim3((ncand + 63u) / 64u), dim3(64), 0, st, bytes, c, d->work);
@@ -533,6 +535,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
 	if(res[4] & 8u) return FLACAMD_E_CAPACITY;
 	if(res[4] != 0) return FLACAMD_E_BAD_STREAM;
+	d->last_ncand = ncand; d->last_nframes = (uint32_t)res[0];
 	return FLACAMD_OK;
 }
 
@@ -557,4 +560,33 @@ extern "C" int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, s
 	if(rc != FLACAMD_OK) return rc;
 	FD_TRY(hipMemcpy(h_pcm, d->d_pcm_stage, (size_t)info[1] * sample_bytes, hipMemcpyDeviceToHost));
 	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_frame_table(flacamd_decoder *d, uint32_t nframes, uint64_t *h_sample_off, uint32_t *h_blocksize,
+	uint64_t *h_number, uint32_t *h_assignment, uint64_t *h_byte_pos, uint64_t *h_byte_end)
+{
+	if(!d || nframes == 0 || nframes != d->last_nframes) return FLACAMD_E_INVALID_ARGUMENT;
+	FD_TRY(hipSetDevice(d->device));
+	const uint32_t nc = d->last_ncand;
+	uint32_t *fo = (uint32_t*)malloc((size_t)nframes * 4u), *bs = (uint32_t*)malloc((size_t)nc * 4u), *info = (uint32_t*)malloc((size_t)nc * 4u);
+	uint64_t *num = (uint64_t*)malloc((size_t)nc * 8u), *pos = (uint64_t*)malloc((size_t)nc * 8u), *end = (uint64_t*)malloc((size_t)nc * 8u);
+	int rc = FLACAMD_OK;
+	if(!fo || !bs || !info || !num || !pos || !end) rc = FLACAMD_E_OUT_OF_MEMORY;
+	else if(hipMemcpy(fo, d->work.frame_of, (size_t)nframes * 4u, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(bs, d->work.cand_bs, (size_t)nc * 4u, hipMemcpyDeviceToHost) != hipSuccess
+		|| hipMemcpy(info, d->work.cand_info, (size_t)nc * 4u, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(num, d->work.cand_num, (size_t)nc * 8u, hipMemcpyDeviceToHost) != hipSuccess
+		|| hipMemcpy(pos, d->work.cand_pos, (size_t)nc * 8u, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(end, d->work.cand_end, (size_t)nc * 8u, hipMemcpyDeviceToHost) != hipSuccess
+		|| (h_sample_off && hipMemcpy(h_sample_off, d->work.sample_off, (size_t)nframes * 8u, hipMemcpyDeviceToHost) != hipSuccess)) rc = FLACAMD_E_DEVICE;
+	else {
+		for(uint32_t r = 0; r < nframes; r++) {
+			const uint32_t ci = fo[r];
+			if(ci >= nc) { rc = FLACAMD_E_DEVICE; break; }
+			if(h_blocksize) h_blocksize[r] = bs[ci];
+			if(h_number) h_number[r] = num[ci];
+			if(h_assignment) h_assignment[r] = (info[ci] >> 4) & 15u;
+			if(h_byte_pos) h_byte_pos[r] = pos[ci];
+			if(h_byte_end) h_byte_end[r] = end[ci];
+		}
+	}
+	free(fo); free(bs); free(info); free(num); free(pos); free(end);
+	return rc;
 }

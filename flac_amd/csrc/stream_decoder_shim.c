@@ -1,0 +1,500 @@
+/* Host side of the libFLAC-style decoder object (include/flac_amd_stream.h) in plain C.
+ *
+ * Keeps the reference's layer-3 semantics - states, init status codes, metadata search with
+ * ID3v2 skipping, STREAMINFO parsing, one frame per process_single, write-callback arguments,
+ * MD5 checking, finish / flush / reset / seek - and hands the frame work (frame_sync_,
+ * read_frame_header_, read_subframe_*, read_residual_partitioned_rice_, restore_signal,
+ * decorrelation, CRC checks) to the device decoder a batch of frames at a time.
+ * Citations are to /root/reference/src/libFLAC/stream_decoder.c unless noted.
+ */
+#define _FILE_OFFSET_BITS 64
+#include "../../include/flac_amd_stream.h"
+#include "../../include/flac_amd_engine.h"
+#include "host_md5.h"
+#include <stdlib.h>
+#include <sys/types.h>
+#include <sys/stat.h>
+
+const char * const FLAC__StreamDecoderStateString[] = { /* :108-119 */
+	"FLAC__STREAM_DECODER_SEARCH_FOR_METADATA", "FLAC__STREAM_DECODER_READ_METADATA", "FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC",
+	"FLAC__STREAM_DECODER_READ_FRAME", "FLAC__STREAM_DECODER_END_OF_STREAM", "FLAC__STREAM_DECODER_OGG_ERROR", "FLAC__STREAM_DECODER_SEEK_ERROR",
+	"FLAC__STREAM_DECODER_ABORTED", "FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR", "FLAC__STREAM_DECODER_UNINITIALIZED" };
+const char * const FLAC__StreamDecoderInitStatusString[] = { /* :121-128 */
+	"FLAC__STREAM_DECODER_INIT_STATUS_OK", "FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER", "FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS",
+	"FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR", "FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE", "FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED" };
+const char * const FLAC__StreamDecoderErrorStatusString[] = { /* :162-167 */
+	"FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC", "FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER", "FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH",
+	"FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM" };
+
+struct FLAC__StreamDecoder {
+	FLAC__StreamDecoderState state;
+	FLAC__bool md5_checking, do_md5, respond_streaminfo;
+	int device; unsigned batch_frames;
+	FLAC__StreamDecoderReadCallback read_cb; FLAC__StreamDecoderSeekCallback seek_cb; FLAC__StreamDecoderTellCallback tell_cb;
+	FLAC__StreamDecoderLengthCallback length_cb; FLAC__StreamDecoderEofCallback eof_cb; FLAC__StreamDecoderWriteCallback write_cb;
+	FLAC__StreamDecoderMetadataCallback metadata_cb; FLAC__StreamDecoderErrorCallback error_cb; void *client_data;
+	FILE *file;
+	FLAC__bool has_streaminfo; FLAC__StreamMetadata streaminfo;
+	FLAC__uint64 samples_decoded, first_frame_offset;
+	/* input window: in[in_pos, in_len) is unread, in[0] sits at absolute stream offset in_base */
+	uint8_t *in; size_t in_cap, in_len, in_pos; FLAC__uint64 in_base; int eof, warned_sync;
+	/* device decoder and the batch it produced */
+	flacamd_decoder *eng; size_t batch_bytes; unsigned eng_frames;
+	int32_t *pcm; size_t pcm_cap;
+	uint64_t *f_off, *f_num, *f_end; uint32_t *f_bs, *f_asg; unsigned q_n, q_i; FLAC__uint64 batch_base;
+	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
+	int32_t *planar; uint8_t *md5_scratch;
+	md5_state md5;
+	FLAC__FrameHeader last;
+	FLAC__bool is_seeking; FLAC__uint64 target_sample;
+};
+
+static void dec_defaults(FLAC__StreamDecoder *d) /* set_defaults_, :1247-1268 */
+{
+	const int device = d->device; const unsigned batch = d->batch_frames;
+	memset(d, 0, sizeof *d);
+	d->device = device; d->batch_frames = batch ? batch : 2048u;
+	d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
+	d->respond_streaminfo = 1; d->md5_checking = 0;
+}
+
+FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
+{
+	FLAC__StreamDecoder *d = (FLAC__StreamDecoder*)calloc(1, sizeof *d);
+	if(d) dec_defaults(d);
+	return d;
+}
+
+static void dec_free(FLAC__StreamDecoder *d)
+{
+	if(d->eng) { flacamd_decoder_destroy(d->eng); d->eng = 0; }
+	free(d->in); d->in = 0; free(d->pcm); d->pcm = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
+	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
+}
+
+void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
+{
+	if(!d) return;
+	(void)FLAC__stream_decoder_finish(d);
+	free(d);
+}
+
+#define DEC_SETTER(name, type, stmt) FLAC__bool name(FLAC__StreamDecoder *d, type value) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; stmt; return 1; }
+DEC_SETTER(FLAC__stream_decoder_set_md5_checking, FLAC__bool, d->md5_checking = value)
+DEC_SETTER(flacamd_stream_decoder_set_device, int, if(value < 0) return 0; d->device = value)
+DEC_SETTER(flacamd_stream_decoder_set_batch_frames, unsigned, if(value == 0) return 0; d->batch_frames = value)
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *d, int type) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED || type != 0) return 0; d->respond_streaminfo = 1; return 1; }
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *d) { (void)d; return 0; }
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *d, int type) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; if(type == 0) d->respond_streaminfo = 0; return 1; }
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *d) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; d->respond_streaminfo = 0; return 1; }
+
+FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *d) { return d->state; }
+const char *FLAC__stream_decoder_get_resolved_state_string(const FLAC__StreamDecoder *d) { return FLAC__StreamDecoderStateString[d->state]; }
+FLAC__bool FLAC__stream_decoder_get_md5_checking(const FLAC__StreamDecoder *d) { return d->md5_checking; }
+FLAC__uint64 FLAC__stream_decoder_get_total_samples(const FLAC__StreamDecoder *d) { return d->has_streaminfo ? d->streaminfo.data.stream_info.total_samples : 0; }
+unsigned FLAC__stream_decoder_get_channels(const FLAC__StreamDecoder *d) { return d->last.channels; }
+FLAC__ChannelAssignment FLAC__stream_decoder_get_channel_assignment(const FLAC__StreamDecoder *d) { return d->last.channel_assignment; }
+unsigned FLAC__stream_decoder_get_bits_per_sample(const FLAC__StreamDecoder *d) { return d->last.bits_per_sample; }
+unsigned FLAC__stream_decoder_get_sample_rate(const FLAC__StreamDecoder *d) { return d->last.sample_rate; }
+unsigned FLAC__stream_decoder_get_blocksize(const FLAC__StreamDecoder *d) { return d->last.blocksize; }
+
+FLAC__bool FLAC__stream_decoder_get_decode_position(const FLAC__StreamDecoder *d, FLAC__uint64 *position) /* :930-950 */
+{
+	if(!d || !position || !d->tell_cb) return 0;
+	*position = d->q_i < d->q_n || d->decode_pos ? d->decode_pos : d->in_base + d->in_pos;
+	return 1;
+}
+
+/* file callbacks (:3315-3390) */
+static FLAC__StreamDecoderReadStatus file_read(const FLAC__StreamDecoder *d, FLAC__byte buffer[], size_t *bytes, void *cd)
+{
+	(void)cd;
+	if(*bytes == 0) return FLAC__STREAM_DECODER_READ_STATUS_ABORT;
+	*bytes = fread(buffer, 1, *bytes, d->file);
+	if(ferror(d->file)) return FLAC__STREAM_DECODER_READ_STATUS_ABORT;
+	return *bytes == 0 ? FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM : FLAC__STREAM_DECODER_READ_STATUS_CONTINUE;
+}
+static FLAC__StreamDecoderSeekStatus file_seek(const FLAC__StreamDecoder *d, FLAC__uint64 off, void *cd)
+{
+	(void)cd;
+	if(d->file == stdin) return FLAC__STREAM_DECODER_SEEK_STATUS_UNSUPPORTED;
+	return fseeko(d->file, (off_t)off, SEEK_SET) < 0 ? FLAC__STREAM_DECODER_SEEK_STATUS_ERROR : FLAC__STREAM_DECODER_SEEK_STATUS_OK;
+}
+static FLAC__StreamDecoderTellStatus file_tell(const FLAC__StreamDecoder *d, FLAC__uint64 *off, void *cd)
+{
+	off_t o; (void)cd;
+	if(d->file == stdin) return FLAC__STREAM_DECODER_TELL_STATUS_UNSUPPORTED;
+	if((o = ftello(d->file)) < 0) return FLAC__STREAM_DECODER_TELL_STATUS_ERROR;
+	*off = (FLAC__uint64)o; return FLAC__STREAM_DECODER_TELL_STATUS_OK;
+}
+static FLAC__StreamDecoderLengthStatus file_length(const FLAC__StreamDecoder *d, FLAC__uint64 *len, void *cd)
+{
+	struct stat st; (void)cd;
+	if(d->file == stdin) return FLAC__STREAM_DECODER_LENGTH_STATUS_UNSUPPORTED;
+	if(fstat(fileno(d->file), &st) != 0) return FLAC__STREAM_DECODER_LENGTH_STATUS_ERROR;
+	*len = (FLAC__uint64)st.st_size; return FLAC__STREAM_DECODER_LENGTH_STATUS_OK;
+}
+static FLAC__bool file_eof(const FLAC__StreamDecoder *d, void *cd) { (void)cd; return feof(d->file) ? 1 : 0; }
+
+static FLAC__StreamDecoderInitStatus dec_init(FLAC__StreamDecoder *d, FLAC__StreamDecoderReadCallback rcb, FLAC__StreamDecoderSeekCallback scb,
+	FLAC__StreamDecoderTellCallback tcb, FLAC__StreamDecoderLengthCallback lcb, FLAC__StreamDecoderEofCallback ecb, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	/* init_stream_internal_ (:364-470) */
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!rcb || !wcb || !errcb || (scb && (!tcb || !lcb || !ecb))) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+	if(flacamd_device_count() <= d->device) return FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR; /* no device to decode on: there is no CPU path */
+	d->read_cb = rcb; d->seek_cb = scb; d->tell_cb = tcb; d->length_cb = lcb; d->eof_cb = ecb; d->write_cb = wcb; d->metadata_cb = mcb; d->error_cb = errcb; d->client_data = client_data;
+	d->in_cap = (size_t)1 << 20; d->in = (uint8_t*)malloc(d->in_cap);
+	d->md5_scratch = (uint8_t*)malloc(65536);
+	if(!d->in || !d->md5_scratch) { dec_free(d); return FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR; }
+	d->in_len = d->in_pos = 0; d->in_base = 0; d->eof = 0; d->warned_sync = 0;
+	d->has_streaminfo = 0; d->samples_decoded = 0; d->first_frame_offset = 0; d->q_n = d->q_i = 0; d->decode_pos = 0;
+	d->do_md5 = d->md5_checking; d->is_seeking = 0;
+	md5_init(&d->md5);
+	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_METADATA;
+	return FLAC__STREAM_DECODER_INIT_STATUS_OK;
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecoder *d, FLAC__StreamDecoderReadCallback rcb, FLAC__StreamDecoderSeekCallback scb,
+	FLAC__StreamDecoderTellCallback tcb, FLAC__StreamDecoderLengthCallback lcb, FLAC__StreamDecoderEofCallback ecb, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	return dec_init(d, rcb, scb, tcb, lcb, ecb, wcb, mcb, errcb, client_data);
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_FILE(FLAC__StreamDecoder *d, FILE *file, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	FLAC__StreamDecoderInitStatus st;
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!wcb || !errcb) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+	d->file = file;
+	st = dec_init(d, file_read, file == stdin ? 0 : file_seek, file == stdin ? 0 : file_tell, file == stdin ? 0 : file_length, file_eof, wcb, mcb, errcb, client_data);
+	if(st != FLAC__STREAM_DECODER_INIT_STATUS_OK) d->file = 0;
+	return st;
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder *d, const char *filename, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	FILE *f; FLAC__StreamDecoderInitStatus st;
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!wcb || !errcb) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+	f = filename ? fopen(filename, "rb") : stdin;
+	if(!f) return FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE;
+	st = FLAC__stream_decoder_init_FILE(d, f, wcb, mcb, errcb, client_data);
+	if(st != FLAC__STREAM_DECODER_INIT_STATUS_OK && f != stdin) fclose(f);
+	return st;
+}
+
+/* ---- input: make at least `need` unread bytes available (fewer at end of stream) */
+static FLAC__bool fill(FLAC__StreamDecoder *d, size_t need)
+{
+	if(d->in_len - d->in_pos >= need) return 1;
+	if(d->in_pos > 0) { /* compact */
+		memmove(d->in, d->in + d->in_pos, d->in_len - d->in_pos);
+		d->in_base += d->in_pos; d->in_len -= d->in_pos; d->in_pos = 0;
+	}
+	if(need > d->in_cap) {
+		uint8_t *nb = (uint8_t*)realloc(d->in, need);
+		if(!nb) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		d->in = nb; d->in_cap = need;
+	}
+	while(d->in_len < need && !d->eof) {
+		size_t n = d->in_cap - d->in_len;
+		const FLAC__StreamDecoderReadStatus st = d->read_cb(d, d->in + d->in_len, &n, d->client_data);
+		if(st == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		d->in_len += n;
+		if(st == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || n == 0) d->eof = 1;
+	}
+	return 1;
+}
+static size_t avail(const FLAC__StreamDecoder *d) { return d->in_len - d->in_pos; }
+
+/* skip n bytes of input that may be larger than the window */
+static FLAC__bool skip_bytes(FLAC__StreamDecoder *d, FLAC__uint64 n)
+{
+	while(n > 0) {
+		size_t k;
+		if(!fill(d, 1)) return 0;
+		if(avail(d) == 0) return 1;
+		k = avail(d) < n ? avail(d) : (size_t)n;
+		d->in_pos += k; n -= k;
+	}
+	return 1;
+}
+
+/* find_metadata_ (:1484-1572): skip an ID3v2 tag, find "fLaC" */
+static FLAC__bool find_metadata(FLAC__StreamDecoder *d)
+{
+	for(;;) {
+		const uint8_t *p;
+		if(!fill(d, 10)) return 0;
+		if(avail(d) < 4) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+		p = d->in + d->in_pos;
+		if(p[0] == 'f' && p[1] == 'L' && p[2] == 'a' && p[3] == 'C') { d->in_pos += 4; d->state = FLAC__STREAM_DECODER_READ_METADATA; return 1; }
+		if(p[0] == 'I' && p[1] == 'D' && p[2] == '3' && avail(d) >= 10) {
+			const FLAC__uint64 skip = 10u + (((FLAC__uint64)(p[6] & 0x7f) << 21) | ((FLAC__uint64)(p[7] & 0x7f) << 14) | ((FLAC__uint64)(p[8] & 0x7f) << 7) | (FLAC__uint64)(p[9] & 0x7f));
+			if(!skip_bytes(d, skip)) return 0;
+			continue;
+		}
+		if(p[0] == 0xff && (p[1] & 0xfe) == 0xf8) { /* a frame before any STREAMINFO: this decoder needs the stream parameters first */
+			d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, d->client_data);
+			d->state = FLAC__STREAM_DECODER_ABORTED;
+			return 0;
+		}
+		if(!d->warned_sync) { d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client_data); d->warned_sync = 1; }
+		d->in_pos++;
+	}
+}
+
+static FLAC__bool start_frames(FLAC__StreamDecoder *d)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	size_t max_frame;
+	if(!d->has_streaminfo || si->channels == 0 || si->max_blocksize == 0) {
+		d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, d->client_data);
+		d->state = FLAC__STREAM_DECODER_ABORTED; return 0;
+	}
+	d->first_frame_offset = d->in_base + d->in_pos;
+	d->decode_pos = d->first_frame_offset;
+	if(!d->eng) {
+		max_frame = 16 + (size_t)si->channels * (((size_t)si->max_blocksize * (si->bits_per_sample + 2) + 7) / 8 + 64) + 2;
+		d->batch_bytes = max_frame * d->batch_frames;
+		if(d->batch_bytes < ((size_t)1 << 16)) d->batch_bytes = (size_t)1 << 16;
+		/* the device decoder's capacity counts every candidate that passes the header checks, and a
+		 * window of batch_bytes may hold more (shorter) frames than batch_frames: leave room, and let
+		 * decode_batch shrink its window when even that is exceeded */
+		d->eng_frames = 2u * d->batch_frames + 256u;
+		d->pcm_cap = (size_t)d->eng_frames * si->max_blocksize;
+		if(flacamd_decoder_create(&d->eng, d->device, si->channels, si->bits_per_sample, si->max_blocksize, d->eng_frames, d->batch_bytes) != FLACAMD_OK) {
+			d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0;
+		}
+		d->pcm = (int32_t*)malloc(sizeof(int32_t) * d->pcm_cap * si->channels);
+		d->f_off = (uint64_t*)malloc(8u * d->eng_frames); d->f_num = (uint64_t*)malloc(8u * d->eng_frames); d->f_end = (uint64_t*)malloc(8u * d->eng_frames);
+		d->f_bs = (uint32_t*)malloc(4u * d->eng_frames); d->f_asg = (uint32_t*)malloc(4u * d->eng_frames);
+		d->planar = (int32_t*)malloc(sizeof(int32_t) * (size_t)si->max_blocksize * si->channels);
+		if(!d->pcm || !d->f_off || !d->f_num || !d->f_end || !d->f_bs || !d->f_asg || !d->planar) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+	}
+	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+	return 1;
+}
+
+/* read_metadata_ (:1574-1790): one block per call */
+static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
+{
+	const uint8_t *p; unsigned type, is_last; FLAC__uint64 length;
+	if(!fill(d, 4)) return 0;
+	if(avail(d) < 4) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+	p = d->in + d->in_pos;
+	is_last = p[0] >> 7; type = p[0] & 0x7f; length = ((FLAC__uint64)p[1] << 16) | ((FLAC__uint64)p[2] << 8) | p[3];
+	d->in_pos += 4;
+	if(type == 0 && length >= 34) { /* stream_decoder.c:1792-1869, layout format.c:68-86 */
+		FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+		FLAC__uint64 x;
+		if(!fill(d, 34)) return 0;
+		if(avail(d) < 34) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+		p = d->in + d->in_pos;
+		d->streaminfo.type = 0; d->streaminfo.is_last = (FLAC__bool)is_last; d->streaminfo.length = (unsigned)length;
+		si->min_blocksize = ((unsigned)p[0] << 8) | p[1]; si->max_blocksize = ((unsigned)p[2] << 8) | p[3];
+		si->min_framesize = ((unsigned)p[4] << 16) | ((unsigned)p[5] << 8) | p[6]; si->max_framesize = ((unsigned)p[7] << 16) | ((unsigned)p[8] << 8) | p[9];
+		x = 0; { int i; for(i = 0; i < 8; i++) x = (x << 8) | p[10 + i]; }
+		si->sample_rate = (unsigned)(x >> 44); si->channels = (unsigned)((x >> 41) & 7u) + 1u; si->bits_per_sample = (unsigned)((x >> 36) & 31u) + 1u;
+		si->total_samples = x & 0xFFFFFFFFFull;
+		memcpy(si->md5sum, p + 18, 16);
+		d->in_pos += 34;
+		if(!skip_bytes(d, length - 34)) return 0;
+		d->has_streaminfo = 1;
+		{ static const uint8_t zero[16] = {0}; if(0 == memcmp(si->md5sum, zero, 16)) d->do_md5 = 0; } /* :1620-1621 */
+		d->last.channels = si->channels; d->last.bits_per_sample = si->bits_per_sample; d->last.sample_rate = si->sample_rate;
+		if(d->respond_streaminfo && d->metadata_cb && !d->is_seeking) d->metadata_cb(d, &d->streaminfo, d->client_data);
+	}
+	else if(!skip_bytes(d, length)) return 0;
+	if(is_last) return start_frames(d);
+	return 1;
+}
+
+/* decode the next batch of frames on the device; leaves q_n > q_i, or a terminal state */
+static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	size_t window; uint64_t info[4] = {0, 0, 0, 0}; int rc;
+	d->q_n = d->q_i = 0;
+	if(si->total_samples > 0 && d->samples_decoded >= si->total_samples) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; } /* :1966-1970 */
+	if(!fill(d, d->batch_bytes)) return 0;
+	if(avail(d) == 0) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+	window = avail(d) < d->batch_bytes ? avail(d) : d->batch_bytes;
+	for(;;) {
+		rc = flacamd_decode_host(d->eng, d->in + d->in_pos, window, d->pcm, FLACAMD_PCM_S32, d->pcm_cap, info);
+		if(rc == FLACAMD_E_CAPACITY && window > 1024u) { window /= 2; continue; } /* more frames in the window than a batch holds */
+		break;
+	}
+	if(rc == FLACAMD_E_BAD_STREAM) {
+		/* no frame, or frames that do not follow one another: at the end of the input this is trailing
+		 * junk (the reference ends the same way, :1987-1999); elsewhere a damaged batch */
+		if(info[0] == 0 && d->eof && window == avail(d)) {
+			if(!d->warned_sync) { d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client_data); d->warned_sync = 1; }
+			d->in_pos = d->in_len; d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1;
+		}
+		d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client_data);
+		d->state = FLAC__STREAM_DECODER_ABORTED; return 0;
+	}
+	if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
+	if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, 0, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+	d->q_n = (unsigned)info[0];
+	d->batch_base = d->in_base + d->in_pos;
+	d->in_pos += (size_t)info[3];
+	return 1;
+}
+
+/* write_audio_frame_to_client_ (:2915-2990) for the next frame of the batch */
+static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	FLAC__Frame frame; const FLAC__int32 *bufs[8]; unsigned r, c, n, ch = si->channels, skip = 0; const int32_t *src; size_t i;
+	if(d->q_i == d->q_n) {
+		if(!decode_batch(d)) return 0;
+		if(d->q_i == d->q_n) return 1; /* end of stream */
+	}
+	r = d->q_i++;
+	n = d->f_bs[r];
+	src = d->pcm + d->f_off[r] * ch;
+	d->decode_pos = d->batch_base + d->f_end[r];
+	memset(&frame, 0, sizeof frame);
+	frame.header.blocksize = n; frame.header.sample_rate = si->sample_rate; frame.header.channels = ch;
+	frame.header.channel_assignment = (FLAC__ChannelAssignment)d->f_asg[r]; frame.header.bits_per_sample = si->bits_per_sample;
+	frame.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
+	frame.header.number.sample_number = d->samples_decoded; /* frame number x fixed blocksize for the streams this decoder takes (:2422-2445) */
+	d->last = frame.header;
+	if(d->do_md5 && deliver) md5_feed_pcm(&d->md5, src, (size_t)n * ch, si->bits_per_sample, d->md5_scratch, 65536);
+	if(d->is_seeking) { /* :2920-2956: drop frames before the target, trim the one that holds it */
+		const FLAC__uint64 first = d->samples_decoded;
+		if(d->target_sample >= first + n) { d->samples_decoded += n; return 1; }
+		skip = (unsigned)(d->target_sample - first);
+		d->is_seeking = 0;
+		frame.header.blocksize = n - skip; frame.header.number.sample_number = first + skip;
+	}
+	d->samples_decoded += n;
+	if(!deliver) return 1;
+	for(c = 0; c < ch; c++) {
+		int32_t *dst = d->planar + (size_t)c * si->max_blocksize;
+		for(i = skip; i < n; i++) dst[i - skip] = src[i * ch + c];
+		bufs[c] = dst;
+	}
+	if(d->write_cb(d, &frame, bufs, d->client_data) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+	return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_process_single(FLAC__StreamDecoder *d) /* :995-1026 */
+{
+	if(!d) return 0;
+	switch(d->state) {
+	case FLAC__STREAM_DECODER_SEARCH_FOR_METADATA: return find_metadata(d);
+	case FLAC__STREAM_DECODER_READ_METADATA: return read_metadata(d);
+	case FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC: case FLAC__STREAM_DECODER_READ_FRAME: return next_frame(d, 1);
+	case FLAC__STREAM_DECODER_END_OF_STREAM: case FLAC__STREAM_DECODER_ABORTED: return 1;
+	default: return 0;
+	}
+}
+
+FLAC__bool FLAC__stream_decoder_process_until_end_of_metadata(FLAC__StreamDecoder *d) /* :1028-1055 */
+{
+	if(!d) return 0;
+	for(;;) {
+		switch(d->state) {
+		case FLAC__STREAM_DECODER_SEARCH_FOR_METADATA: if(!find_metadata(d)) return 0; break;
+		case FLAC__STREAM_DECODER_READ_METADATA: if(!read_metadata(d)) return 0; break;
+		case FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC: case FLAC__STREAM_DECODER_READ_FRAME: case FLAC__STREAM_DECODER_END_OF_STREAM: case FLAC__STREAM_DECODER_ABORTED: return 1;
+		default: return 0;
+		}
+	}
+}
+
+FLAC__bool FLAC__stream_decoder_process_until_end_of_stream(FLAC__StreamDecoder *d) /* :1057-1090 */
+{
+	if(!d) return 0;
+	for(;;) {
+		switch(d->state) {
+		case FLAC__STREAM_DECODER_SEARCH_FOR_METADATA: if(!find_metadata(d)) return 0; break;
+		case FLAC__STREAM_DECODER_READ_METADATA: if(!read_metadata(d)) return 0; break;
+		case FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC: case FLAC__STREAM_DECODER_READ_FRAME: if(!next_frame(d, 1)) return 0; break;
+		case FLAC__STREAM_DECODER_END_OF_STREAM: case FLAC__STREAM_DECODER_ABORTED: return 1;
+		default: return 0;
+		}
+	}
+}
+
+FLAC__bool FLAC__stream_decoder_skip_single_frame(FLAC__StreamDecoder *d) /* :1092-1122 */
+{
+	if(!d) return 0;
+	for(;;) {
+		switch(d->state) {
+		case FLAC__STREAM_DECODER_SEARCH_FOR_METADATA: case FLAC__STREAM_DECODER_READ_METADATA: return 0; /* the caller must be past the metadata */
+		case FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC: case FLAC__STREAM_DECODER_READ_FRAME: d->do_md5 = 0; return next_frame(d, 0);
+		case FLAC__STREAM_DECODER_END_OF_STREAM: case FLAC__STREAM_DECODER_ABORTED: return 1;
+		default: return 0;
+		}
+	}
+}
+
+FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *d) /* :952-973 */
+{
+	if(!d || d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
+	d->samples_decoded = 0; d->do_md5 = 0;
+	d->in_base += d->in_len; d->in_len = d->in_pos = 0; d->eof = 0; d->q_n = d->q_i = 0;
+	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+	return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *d) /* :975-1040 */
+{
+	if(!FLAC__stream_decoder_flush(d)) return 0;
+	if(d->file == stdin) return 0;
+	if(d->seek_cb && d->seek_cb(d, 0, d->client_data) == FLAC__STREAM_DECODER_SEEK_STATUS_ERROR) return 0;
+	d->in_base = 0; d->warned_sync = 0; d->decode_pos = 0;
+	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_METADATA;
+	d->has_streaminfo = 0; d->first_frame_offset = 0;
+	d->do_md5 = d->md5_checking; md5_init(&d->md5);
+	return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *d, FLAC__uint64 sample) /* :1124-1180 */
+{
+	FLAC__uint64 total;
+	if(!d) return 0;
+	if(d->state != FLAC__STREAM_DECODER_SEARCH_FOR_METADATA && d->state != FLAC__STREAM_DECODER_READ_METADATA && d->state != FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC
+		&& d->state != FLAC__STREAM_DECODER_READ_FRAME && d->state != FLAC__STREAM_DECODER_END_OF_STREAM) return 0;
+	if(!d->seek_cb) return 0;
+	d->do_md5 = 0;
+	d->is_seeking = 1; /* keeps the metadata callback quiet while the head is read (:1140-1150) */
+	if(d->state == FLAC__STREAM_DECODER_SEARCH_FOR_METADATA || d->state == FLAC__STREAM_DECODER_READ_METADATA) {
+		if(!FLAC__stream_decoder_process_until_end_of_metadata(d)) { d->is_seeking = 0; return 0; }
+	}
+	total = FLAC__stream_decoder_get_total_samples(d);
+	if(!d->has_streaminfo || (total > 0 && sample >= total)) { d->is_seeking = 0; return 0; }
+	/* every frame decodes independently and a batch costs milliseconds, so the target is found by
+	 * decoding forward from the first frame rather than by the reference's bisection (:2992-3225) */
+	if(d->seek_cb(d, d->first_frame_offset, d->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+	d->in_base = d->first_frame_offset; d->in_len = d->in_pos = 0; d->eof = 0; d->q_n = d->q_i = 0; d->samples_decoded = 0;
+	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+	d->target_sample = sample;
+	while(d->is_seeking) {
+		if(!next_frame(d, 1)) { d->is_seeking = 0; return 0; }
+		if(d->state == FLAC__STREAM_DECODER_END_OF_STREAM && d->is_seeking) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+	}
+	return 1;
+}
+
+FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *d) /* :640-695 */
+{
+	FLAC__bool md5_failed = 0; uint8_t digest[16];
+	if(!d) return 0;
+	if(d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 1;
+	md5_final(&d->md5, digest);
+	if(d->do_md5 && d->has_streaminfo && memcmp(d->streaminfo.data.stream_info.md5sum, digest, 16)) md5_failed = 1;
+	if(d->file) { if(d->file != stdin) fclose(d->file); d->file = 0; }
+	dec_free(d);
+	dec_defaults(d);
+	return !md5_failed;
+}

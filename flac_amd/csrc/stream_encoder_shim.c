@@ -29,48 +29,7 @@ const char * const FLAC__StreamEncoderInitStatusString[] = { /* :470-485 */
 	"FLAC__STREAM_ENCODER_INIT_STATUS_BLOCK_SIZE_TOO_SMALL_FOR_LPC_ORDER", "FLAC__STREAM_ENCODER_INIT_STATUS_NOT_STREAMABLE",
 	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA", "FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED" };
 
-/* ---- MD5 (md5.c), fed with the PCM bytes as format_input_ lays them out (md5.c:273-389) */
-typedef struct { uint32_t h[4]; uint64_t nbytes; uint8_t buf[64]; } md5_state;
-static const uint32_t md5_k[64] = {
-	0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
-	0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
-	0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
-	0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
-static const uint8_t md5_s[64] = { 7,12,17,22,7,12,17,22,7,12,17,22,7,12,17,22, 5,9,14,20,5,9,14,20,5,9,14,20,5,9,14,20, 4,11,16,23,4,11,16,23,4,11,16,23,4,11,16,23, 6,10,15,21,6,10,15,21,6,10,15,21,6,10,15,21 };
-static void md5_block(md5_state *m, const uint8_t *p)
-{
-	uint32_t w[16], a = m->h[0], b = m->h[1], c = m->h[2], d = m->h[3]; int i;
-	for(i = 0; i < 16; i++) w[i] = (uint32_t)p[4*i] | (uint32_t)p[4*i+1] << 8 | (uint32_t)p[4*i+2] << 16 | (uint32_t)p[4*i+3] << 24;
-	for(i = 0; i < 64; i++) {
-		uint32_t f, t; int g;
-		if(i < 16) { f = (b & c) | (~b & d); g = i; }
-		else if(i < 32) { f = (d & b) | (~d & c); g = (5*i + 1) & 15; }
-		else if(i < 48) { f = b ^ c ^ d; g = (3*i + 5) & 15; }
-		else { f = c ^ (b | ~d); g = (7*i) & 15; }
-		t = d; d = c; c = b;
-		f += a + md5_k[i] + w[g];
-		b += (f << md5_s[i]) | (f >> (32 - md5_s[i]));
-		a = t;
-	}
-	m->h[0] += a; m->h[1] += b; m->h[2] += c; m->h[3] += d;
-}
-static void md5_init(md5_state *m) { m->h[0] = 0x67452301; m->h[1] = 0xefcdab89; m->h[2] = 0x98badcfe; m->h[3] = 0x10325476; m->nbytes = 0; }
-static void md5_update(md5_state *m, const uint8_t *p, size_t n)
-{
-	size_t fill = (size_t)(m->nbytes & 63);
-	m->nbytes += n;
-	if(fill) { size_t t = 64 - fill; if(t > n) t = n; memcpy(m->buf + fill, p, t); p += t; n -= t; if(fill + t < 64) return; md5_block(m, m->buf); }
-	while(n >= 64) { md5_block(m, p); p += 64; n -= 64; }
-	if(n) memcpy(m->buf, p, n);
-}
-static void md5_final(md5_state *m, uint8_t out[16])
-{
-	const uint64_t bits = m->nbytes * 8; uint8_t pad[72]; const size_t fill = (size_t)(m->nbytes & 63), n = (fill < 56 ? 56 - fill : 120 - fill); int i;
-	memset(pad, 0, sizeof pad); pad[0] = 0x80;
-	for(i = 0; i < 8; i++) pad[n + i] = (uint8_t)(bits >> (8*i));
-	md5_update(m, pad, n + 8);
-	for(i = 0; i < 16; i++) out[i] = (uint8_t)(m->h[i >> 2] >> (8 * (i & 3)));
-}
+#include "host_md5.h"
 
 /* ---- the object */
 struct FLAC__StreamEncoder {
@@ -391,13 +350,7 @@ static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final
 
 static void md5_feed(FLAC__StreamEncoder *e, const int32_t *interleaved, size_t nvalues)
 {
-	const unsigned nb = (e->p.bits_per_sample + 7) / 8; size_t i, fill = 0; uint8_t *t = e->md5_scratch; unsigned b;
-	for(i = 0; i < nvalues; i++) {
-		const uint32_t v = (uint32_t)interleaved[i];
-		for(b = 0; b < nb; b++) t[fill++] = (uint8_t)(v >> (8 * b));
-		if(fill + 4 > (size_t)65536 * 4) { md5_update(&e->md5, t, fill); fill = 0; }
-	}
-	if(fill) md5_update(&e->md5, t, fill);
+	md5_feed_pcm(&e->md5, interleaved, nvalues, e->p.bits_per_sample, e->md5_scratch, (size_t)65536 * 4);
 }
 
 /* queue `n` wide samples already interleaved at the queue tail, then flush whole batches.

@@ -223,3 +223,180 @@ class FileEncoder(StreamEncoder):
         if status == INIT_OK:
             self._keep = (cb,)
         return status
+
+
+# ---- decoder object -----------------------------------------------------------------------
+
+(DEC_SEARCH_FOR_METADATA, DEC_READ_METADATA, DEC_SEARCH_FOR_FRAME_SYNC, DEC_READ_FRAME, DEC_END_OF_STREAM, DEC_OGG_ERROR, DEC_SEEK_ERROR,
+ DEC_ABORTED, DEC_MEMORY_ALLOCATION_ERROR, DEC_UNINITIALIZED) = range(10)
+(DEC_INIT_OK, DEC_INIT_UNSUPPORTED_CONTAINER, DEC_INIT_INVALID_CALLBACKS, DEC_INIT_MEMORY_ALLOCATION_ERROR, DEC_INIT_ERROR_OPENING_FILE,
+ DEC_INIT_ALREADY_INITIALIZED) = range(6)
+ERR_LOST_SYNC, ERR_BAD_HEADER, ERR_FRAME_CRC_MISMATCH, ERR_UNPARSEABLE_STREAM = range(4)
+
+
+class _FrameNumber(C.Union):
+    _fields_ = [("frame_number", C.c_uint32), ("sample_number", C.c_uint64)]
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("blocksize", C.c_uint), ("sample_rate", C.c_uint), ("channels", C.c_uint), ("channel_assignment", C.c_int),
+                ("bits_per_sample", C.c_uint), ("number_type", C.c_int), ("number", _FrameNumber), ("crc", C.c_uint8)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("header", FrameHeader), ("footer_crc", C.c_uint16)]
+
+
+D_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t), C.c_void_p)
+D_SEEK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
+D_TELL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+D_LENGTH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+D_EOF_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+D_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Frame), C.POINTER(C.POINTER(C.c_int32)), C.c_void_p)
+D_META_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(StreamMetadata), C.c_void_p)
+D_ERROR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+_dec_bound = False
+
+
+def _dec_lib():
+    global _dec_bound
+    L = engine.lib()
+    if not _dec_bound:
+        vp = C.c_void_p
+        L.FLAC__stream_decoder_new.restype = vp
+        L.FLAC__stream_decoder_delete.argtypes = [vp]
+        L.FLAC__stream_decoder_delete.restype = None
+        for n in ("set_md5_checking", "set_metadata_respond", "set_metadata_ignore"):
+            getattr(L, "FLAC__stream_decoder_" + n).argtypes = [vp, C.c_int]
+        for n in ("set_metadata_respond_all", "set_metadata_ignore_all", "finish", "flush", "reset", "process_single",
+                  "process_until_end_of_metadata", "process_until_end_of_stream", "skip_single_frame", "get_state", "get_md5_checking",
+                  "get_channels", "get_channel_assignment", "get_bits_per_sample", "get_sample_rate", "get_blocksize"):
+            getattr(L, "FLAC__stream_decoder_" + n).argtypes = [vp]
+        L.FLAC__stream_decoder_get_total_samples.argtypes = [vp]
+        L.FLAC__stream_decoder_get_total_samples.restype = C.c_uint64
+        L.FLAC__stream_decoder_get_resolved_state_string.argtypes = [vp]
+        L.FLAC__stream_decoder_get_resolved_state_string.restype = C.c_char_p
+        L.FLAC__stream_decoder_get_decode_position.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.FLAC__stream_decoder_seek_absolute.argtypes = [vp, C.c_uint64]
+        L.FLAC__stream_decoder_init_stream.argtypes = [vp, D_READ_CB, D_SEEK_CB, D_TELL_CB, D_LENGTH_CB, D_EOF_CB, D_WRITE_CB, D_META_CB, D_ERROR_CB, vp]
+        L.FLAC__stream_decoder_init_file.argtypes = [vp, C.c_char_p, D_WRITE_CB, D_META_CB, D_ERROR_CB, vp]
+        L.flacamd_stream_decoder_set_device.argtypes = [vp, C.c_int]
+        L.flacamd_stream_decoder_set_batch_frames.argtypes = [vp, C.c_uint]
+        _dec_bound = True
+    return L
+
+
+class StreamDecoder:
+    """FLAC::Decoder::Stream (include/FLAC++/decoder.h:97-208) over bytes held in memory (or a file):
+    collects what the callbacks deliver.  frames: list of (header dict, int32 array (channels, blocksize))."""
+
+    def __init__(self, data=None, seekable=True, read_chunk=None):
+        self._lib = _dec_lib()
+        self._h = C.c_void_p(self._lib.FLAC__stream_decoder_new())
+        self.data, self.pos, self.seekable, self.read_chunk = data, 0, seekable, read_chunk
+        self.frames, self.errors, self.streaminfo = [], [], None
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            self._lib.FLAC__stream_decoder_delete(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        if name.startswith(("set_", "get_", "process_", "skip_", "finish", "flush", "reset")):
+            prefix = "flacamd_stream_decoder_" if name in ("set_device", "set_batch_frames") else "FLAC__stream_decoder_"
+            fn = getattr(self._lib, prefix + name)
+            if name.startswith("set_") and name not in ("set_metadata_respond_all", "set_metadata_ignore_all"):
+                return lambda value: bool(fn(self._h, int(value)))
+            if name.startswith("get_"):
+                return lambda: fn(self._h)
+            return lambda: bool(fn(self._h))
+        raise AttributeError(name)
+
+    def get_resolved_state_string(self):
+        return self._lib.FLAC__stream_decoder_get_resolved_state_string(self._h).decode()
+
+    def get_decode_position(self):
+        v = C.c_uint64(0)
+        return int(v.value) if self._lib.FLAC__stream_decoder_get_decode_position(self._h, C.byref(v)) else None
+
+    def seek_absolute(self, sample):
+        return bool(self._lib.FLAC__stream_decoder_seek_absolute(self._h, sample))
+
+    # callbacks (override write_callback to stop early etc.)
+    def write_callback(self, header, pcm):
+        self.frames.append((header, pcm))
+        return 0
+
+    def _callbacks(self):
+        def w(_d, frame, bufs, _cd):
+            h = frame.contents.header
+            hdr = dict(blocksize=h.blocksize, sample_rate=h.sample_rate, channels=h.channels, channel_assignment=h.channel_assignment,
+                       bits_per_sample=h.bits_per_sample, number_type=h.number_type, sample_number=h.number.sample_number)
+            pcm = np.stack([np.ctypeslib.as_array(bufs[c], shape=(h.blocksize,)).copy() for c in range(h.channels)])
+            return int(self.write_callback(hdr, pcm) or 0)
+
+        def m(_d, md, _cd):
+            si = md.contents.data.stream_info
+            self.streaminfo = dict(min_blocksize=si.min_blocksize, max_blocksize=si.max_blocksize, min_framesize=si.min_framesize,
+                                   max_framesize=si.max_framesize, sample_rate=si.sample_rate, channels=si.channels,
+                                   bits_per_sample=si.bits_per_sample, total_samples=si.total_samples, md5sum=bytes(si.md5sum))
+
+        def e(_d, status, _cd):
+            self.errors.append(status)
+
+        return D_WRITE_CB(w), D_META_CB(m), D_ERROR_CB(e)
+
+    def init(self):
+        def r(_d, buf, pbytes, _cd):
+            want = pbytes[0] if self.read_chunk is None else min(pbytes[0], self.read_chunk)
+            chunk = self.data[self.pos:self.pos + want]
+            C.memmove(buf, chunk, len(chunk))
+            self.pos += len(chunk)
+            pbytes[0] = len(chunk)
+            return 1 if len(chunk) == 0 else 0
+
+        def s(_d, off, _cd):
+            self.pos = off
+            return 0
+
+        def t(_d, poff, _cd):
+            poff[0] = self.pos
+            return 0
+
+        def ln(_d, plen, _cd):
+            plen[0] = len(self.data)
+            return 0
+
+        def eof(_d, _cd):
+            return 1 if self.pos >= len(self.data) else 0
+
+        wcb, mcb, ecb = self._callbacks()
+        if self.seekable:
+            cbs = (D_READ_CB(r), D_SEEK_CB(s), D_TELL_CB(t), D_LENGTH_CB(ln), D_EOF_CB(eof), wcb, mcb, ecb)
+        else:
+            cbs = (D_READ_CB(r), D_SEEK_CB(), D_TELL_CB(), D_LENGTH_CB(), D_EOF_CB(), wcb, mcb, ecb)
+        status = int(self._lib.FLAC__stream_decoder_init_stream(self._h, *cbs, None))
+        if status == DEC_INIT_OK:
+            self._keep = cbs
+        return status
+
+    def init_file(self, filename):
+        cbs = self._callbacks()
+        status = int(self._lib.FLAC__stream_decoder_init_file(self._h, filename.encode(), *cbs, None))
+        if status == DEC_INIT_OK:
+            self._keep = cbs
+        return status
+
+    def pcm(self):
+        """all delivered frames as (samples, channels) int32"""
+        if not self.frames:
+            return np.zeros((0, 0), np.int32)
+        return np.concatenate([p for _, p in self.frames], axis=1).T.copy()

@@ -158,6 +158,13 @@ int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, size_t nbytes
 int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, size_t nbytes,
 	void *h_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4]);
 
+/* Per frame of the last successful decode, in stream order (what read_frame_header_ leaves in
+ * FLAC__FrameHeader, stream_decoder.c:2147-2454): first wide sample within the batch, blocksize, the
+ * frame/sample number coded in the header, channel assignment (0 independent, 1 left/side,
+ * 2 right/side, 3 mid/side) and the byte range of the frame within the input.  Any pointer may be NULL. */
+int flacamd_decoder_frame_table(flacamd_decoder *d, uint32_t nframes, uint64_t *h_sample_off, uint32_t *h_blocksize,
+	uint64_t *h_number, uint32_t *h_assignment, uint64_t *h_byte_pos, uint64_t *h_byte_end);
+
 const char *flacamd_strerror(int code);
 /* Text of the last failing HIP call on this thread ("" if none). */
 const char *flacamd_last_error(void);

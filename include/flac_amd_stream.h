@@ -159,6 +159,132 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *encoder);
 FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *encoder, int device);
 FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *encoder, unsigned frames);
 
+/* ======================================================================================
+ * libFLAC-style stream decoder object over the frame-parallel device decoder.
+ *
+ * Names, argument meaning, callback types and state / status values of the reference's
+ * public decoder API (include/FLAC/stream_decoder.h:203-437 enums, :516-726 callbacks,
+ * :742-1551 functions; defined in src/libFLAC/stream_decoder.c:284-1245).  The client's read
+ * callback is drained in large pieces, whole batches of frames are decoded on the device
+ * (sync search, header CRC-8, Rice decoding, prediction restore, CRC-16, decorrelation), and
+ * the reference's per-frame write_audio_frame_to_client_ logic (stream_decoder.c:2915-2990) is
+ * replayed frame by frame in stream order: the write callback sees the same FLAC__FrameHeader
+ * fields and the same planar FLAC__int32 buffers as with the reference.
+ *
+ * Differences, none silent: only the STREAMINFO block is delivered to the metadata callback
+ * (requests for other block types return false); Ogg transport is not provided; a stream must
+ * begin with STREAMINFO; a batch that contains corrupt frames is reported through the error
+ * callback and decoding stops (state ABORTED) instead of resynchronising inside the batch;
+ * FLAC__Frame carries the header and the footer CRC but no per-subframe records.
+ * ====================================================================================== */
+
+typedef enum {
+	FLAC__STREAM_DECODER_SEARCH_FOR_METADATA = 0,
+	FLAC__STREAM_DECODER_READ_METADATA,
+	FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC,
+	FLAC__STREAM_DECODER_READ_FRAME,
+	FLAC__STREAM_DECODER_END_OF_STREAM,
+	FLAC__STREAM_DECODER_OGG_ERROR,
+	FLAC__STREAM_DECODER_SEEK_ERROR,
+	FLAC__STREAM_DECODER_ABORTED,
+	FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR,
+	FLAC__STREAM_DECODER_UNINITIALIZED
+} FLAC__StreamDecoderState;
+
+typedef enum {
+	FLAC__STREAM_DECODER_INIT_STATUS_OK = 0,
+	FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER,
+	FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS,
+	FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR,
+	FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE,
+	FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED
+} FLAC__StreamDecoderInitStatus;
+
+typedef enum { FLAC__STREAM_DECODER_READ_STATUS_CONTINUE, FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM, FLAC__STREAM_DECODER_READ_STATUS_ABORT } FLAC__StreamDecoderReadStatus;
+typedef enum { FLAC__STREAM_DECODER_SEEK_STATUS_OK, FLAC__STREAM_DECODER_SEEK_STATUS_ERROR, FLAC__STREAM_DECODER_SEEK_STATUS_UNSUPPORTED } FLAC__StreamDecoderSeekStatus;
+typedef enum { FLAC__STREAM_DECODER_TELL_STATUS_OK, FLAC__STREAM_DECODER_TELL_STATUS_ERROR, FLAC__STREAM_DECODER_TELL_STATUS_UNSUPPORTED } FLAC__StreamDecoderTellStatus;
+typedef enum { FLAC__STREAM_DECODER_LENGTH_STATUS_OK, FLAC__STREAM_DECODER_LENGTH_STATUS_ERROR, FLAC__STREAM_DECODER_LENGTH_STATUS_UNSUPPORTED } FLAC__StreamDecoderLengthStatus;
+typedef enum { FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE, FLAC__STREAM_DECODER_WRITE_STATUS_ABORT } FLAC__StreamDecoderWriteStatus;
+typedef enum {
+	FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC,
+	FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER,
+	FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH,
+	FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM
+} FLAC__StreamDecoderErrorStatus;
+
+extern const char * const FLAC__StreamDecoderStateString[];
+extern const char * const FLAC__StreamDecoderInitStatusString[];
+extern const char * const FLAC__StreamDecoderErrorStatusString[];
+
+/* include/FLAC/format.h:376-443 */
+typedef enum {
+	FLAC__CHANNEL_ASSIGNMENT_INDEPENDENT = 0,
+	FLAC__CHANNEL_ASSIGNMENT_LEFT_SIDE = 1,
+	FLAC__CHANNEL_ASSIGNMENT_RIGHT_SIDE = 2,
+	FLAC__CHANNEL_ASSIGNMENT_MID_SIDE = 3
+} FLAC__ChannelAssignment;
+typedef enum { FLAC__FRAME_NUMBER_TYPE_FRAME_NUMBER, FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER } FLAC__FrameNumberType;
+typedef struct {
+	unsigned blocksize;
+	unsigned sample_rate;
+	unsigned channels;
+	FLAC__ChannelAssignment channel_assignment;
+	unsigned bits_per_sample;
+	FLAC__FrameNumberType number_type;   /* always SAMPLE_NUMBER when handed to the client (stream_decoder.c:2422-2445) */
+	union { FLAC__uint32 frame_number; FLAC__uint64 sample_number; } number;
+	FLAC__byte crc;
+} FLAC__FrameHeader;
+typedef struct { uint16_t crc; } FLAC__FrameFooter;
+typedef struct { FLAC__FrameHeader header; FLAC__FrameFooter footer; } FLAC__Frame;
+
+typedef struct FLAC__StreamDecoder FLAC__StreamDecoder;
+
+typedef FLAC__StreamDecoderReadStatus (*FLAC__StreamDecoderReadCallback)(const FLAC__StreamDecoder *decoder, FLAC__byte buffer[], size_t *bytes, void *client_data);
+typedef FLAC__StreamDecoderSeekStatus (*FLAC__StreamDecoderSeekCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 absolute_byte_offset, void *client_data);
+typedef FLAC__StreamDecoderTellStatus (*FLAC__StreamDecoderTellCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 *absolute_byte_offset, void *client_data);
+typedef FLAC__StreamDecoderLengthStatus (*FLAC__StreamDecoderLengthCallback)(const FLAC__StreamDecoder *decoder, FLAC__uint64 *stream_length, void *client_data);
+typedef FLAC__bool (*FLAC__StreamDecoderEofCallback)(const FLAC__StreamDecoder *decoder, void *client_data);
+typedef FLAC__StreamDecoderWriteStatus (*FLAC__StreamDecoderWriteCallback)(const FLAC__StreamDecoder *decoder, const FLAC__Frame *frame, const FLAC__int32 * const buffer[], void *client_data);
+typedef void (*FLAC__StreamDecoderMetadataCallback)(const FLAC__StreamDecoder *decoder, const FLAC__StreamMetadata *metadata, void *client_data);
+typedef void (*FLAC__StreamDecoderErrorCallback)(const FLAC__StreamDecoder *decoder, FLAC__StreamDecoderErrorStatus status, void *client_data);
+
+FLAC__StreamDecoder *FLAC__stream_decoder_new(void);
+void FLAC__stream_decoder_delete(FLAC__StreamDecoder *decoder);
+
+FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *decoder, FLAC__bool value);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *decoder, int type);   /* only type 0 (STREAMINFO) */
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *decoder);          /* false: other block types are not delivered */
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *decoder, int type);
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *decoder);
+
+FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *decoder);
+const char *FLAC__stream_decoder_get_resolved_state_string(const FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_get_md5_checking(const FLAC__StreamDecoder *decoder);
+FLAC__uint64 FLAC__stream_decoder_get_total_samples(const FLAC__StreamDecoder *decoder);
+unsigned FLAC__stream_decoder_get_channels(const FLAC__StreamDecoder *decoder);
+FLAC__ChannelAssignment FLAC__stream_decoder_get_channel_assignment(const FLAC__StreamDecoder *decoder);
+unsigned FLAC__stream_decoder_get_bits_per_sample(const FLAC__StreamDecoder *decoder);
+unsigned FLAC__stream_decoder_get_sample_rate(const FLAC__StreamDecoder *decoder);
+unsigned FLAC__stream_decoder_get_blocksize(const FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_get_decode_position(const FLAC__StreamDecoder *decoder, FLAC__uint64 *position);
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecoder *decoder, FLAC__StreamDecoderReadCallback read_callback, FLAC__StreamDecoderSeekCallback seek_callback, FLAC__StreamDecoderTellCallback tell_callback, FLAC__StreamDecoderLengthCallback length_callback, FLAC__StreamDecoderEofCallback eof_callback, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_FILE(FLAC__StreamDecoder *decoder, FILE *file, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder *decoder, const char *filename, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+
+FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_single(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_until_end_of_metadata(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_process_until_end_of_stream(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_skip_single_frame(FLAC__StreamDecoder *decoder);
+FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *decoder, FLAC__uint64 sample);
+
+/* additions of this implementation: HIP device (default 0), frames per device batch (default 2048) */
+FLAC__bool flacamd_stream_decoder_set_device(FLAC__StreamDecoder *decoder, int device);
+FLAC__bool flacamd_stream_decoder_set_batch_frames(FLAC__StreamDecoder *decoder, unsigned frames);
+
 #ifdef __cplusplus
 }
 #endif

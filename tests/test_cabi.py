@@ -26,7 +26,9 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     stream_names = _declared_symbols("flac_amd_stream.h")
     assert len(stream_names) >= 50 and "FLAC__stream_encoder_process_interleaved" in stream_names
-    for n in names + stream_names + ["FLAC__StreamEncoderStateString", "FLAC__StreamEncoderInitStatusString"]:
+    assert "FLAC__stream_decoder_process_until_end_of_stream" in stream_names and "flacamd_decoder_frame_table" in names
+    for n in names + stream_names + ["FLAC__StreamEncoderStateString", "FLAC__StreamEncoderInitStatusString", "FLAC__StreamDecoderStateString",
+                                     "FLAC__StreamDecoderInitStatusString", "FLAC__StreamDecoderErrorStatusString"]:
         assert hasattr(lib, n), n
 
 
@@ -143,3 +145,22 @@ def test_stream_encoder_requires_a_write_callback_and_a_device():
         assert not m.process_interleaved(np.zeros((10, 2), np.int32))
         m.close()
     e.close()
+
+
+def test_stream_decoder_init_checks_and_no_cpu_path():
+    """init_stream_internal_'s callback checks (stream_decoder.c:364-395); no device, no decoder."""
+    from flac_amd import stream
+    L = engine.lib()
+    d = stream.StreamDecoder(b"", seekable=False)
+    assert d.get_state() == stream.DEC_UNINITIALIZED and d.get_resolved_state_string() == "FLAC__STREAM_DECODER_UNINITIALIZED"
+    none = (stream.D_READ_CB(), stream.D_SEEK_CB(), stream.D_TELL_CB(), stream.D_LENGTH_CB(), stream.D_EOF_CB(), stream.D_WRITE_CB(), stream.D_META_CB(), stream.D_ERROR_CB())
+    assert L.FLAC__stream_decoder_init_stream(d._h, *none, None) == stream.DEC_INIT_INVALID_CALLBACKS
+    rd, wr, er = stream.D_READ_CB(lambda *a: 1), stream.D_WRITE_CB(lambda *a: 0), stream.D_ERROR_CB(lambda *a: None)
+    # a seek callback without tell / length / eof is refused
+    assert L.FLAC__stream_decoder_init_stream(d._h, rd, stream.D_SEEK_CB(lambda *a: 0), stream.D_TELL_CB(), stream.D_LENGTH_CB(), stream.D_EOF_CB(), wr, stream.D_META_CB(), er, None) == stream.DEC_INIT_INVALID_CALLBACKS
+    assert d.set_md5_checking(1) and d.get_md5_checking() == 1
+    assert not d.set_metadata_respond(4) and d.set_metadata_respond(0) and not d.set_metadata_respond_all()
+    assert not d.process_single() and d.finish()
+    if engine.device_count() == 0:
+        assert d.init() == stream.DEC_INIT_MEMORY_ALLOCATION_ERROR and d.get_state() == stream.DEC_UNINITIALIZED
+    d.close()
