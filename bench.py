@@ -27,6 +27,26 @@ RATE = 44100
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
 
 
+# kernel that runs each timed stage for this workload (16-bit stereo, blocksize 4096)
+KERNEL_OF_STAGE = {"prep": "fa_prep_stereo16_kernel", "autoc": "fa_autoc_ms16_kernel<13>", "model": "fa_model_kernel<12>",
+                   "search": "fa_search_fast_kernel<unsigned int, 1, 1>", "pack": "fa_pack_fast_kernel<2>", "gather": "fa_gather_kernel"}
+
+
+def pmc_traffic(kernel, minutes):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/r1_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    runs, FETCH_SIZE doubled as measured for gfx950), or None when no pass covers it."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+            summ = json.load(f)
+        if summ.get("minutes") != minutes:
+            return None
+        k = summ["kernels"].get(kernel)
+        return None if k is None else int(k["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def build_workload(seconds_base=60, repeats=60):
     """One hour = a 60 s seeded synthetic programme tiled 60 times (int16 stereo)."""
     from flac_amd import synth
@@ -49,7 +69,8 @@ def cpu_baseline(base_pcm, budget_s=12.0):
         fp, _ = ob.make_params(2, 16, RATE, level=8)
         fn = lambda: ob.oracle_encode(fp, pcm32)
         kind = "port"
-    fn()  # warm caches
+    first = fn()  # warm caches
+    ref_bytes = sum(len(f) for f in first["frames"])
     t0 = time.perf_counter()
     passes = 0
     best = 1e30
@@ -62,7 +83,7 @@ def cpu_baseline(base_pcm, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s or passes >= 24:
             break
     single = n / best / 1e6
-    out = {"value": round(single, 3), "unit": "MSamples/s", "cores": 1, "kind": kind,
+    out = {"value": round(single, 3), "unit": "MSamples/s", "cores": 1, "kind": kind, "ref_bytes_60s": ref_bytes,
            "sample": "%d passes of flac -8 over a 60 s 16/44.1 stereo programme (%d wide samples), best pass, single stream" % (passes, n)}
     # all host cores: one process per core of this job's CPU share
     try:
@@ -108,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--minutes", type=int, default=60, help="audio minutes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -172,6 +194,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- extra, outside the timed region: decode the stream just produced on the device and
+    # check the round trip; compressed size against the reference's for the 60 s base programme
+    decode = None
+    if rank == 0 and not args.no_decode:
+        try:
+            dec = engine.Decoder(2, 16, FRAME, int(nframes * 1.25) + 64, total_bytes + 64, device=local)
+            d_back = torch.empty((nsamples, 2), dtype=torch.int16, device=dev)
+            d_in = d_out[:total_bytes]
+            dec.decode_device(d_in.data_ptr(), total_bytes, d_back.data_ptr(), engine.PCM_S16, nsamples)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                info = dec.decode_device(d_in.data_ptr(), total_bytes, d_back.data_ptr(), engine.PCM_S16, nsamples)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 3
+            decode = {"value": round(nsamples / dt / 1e6, 2), "unit": "MSamples/s", "ms": round(dt * 1e3, 3), "frames": info["frames"],
+                      "round_trip_bit_exact": bool(torch.equal(d_back, d_pcm))}
+            dec.close()
+            del d_back
+        except Exception as ex:  # reported, never hidden
+            decode = {"error": str(ex)}
+    size_delta = None
+    if rank == 0 and cpu is not None and "ref_bytes_60s" in cpu:
+        enc60 = engine.Encoder(params, max_frames=(len(base) + FRAME - 1) // FRAME, device=local)
+        frames60, _ = enc60.encode_host(base)
+        enc60.close()
+        size_delta = (sum(map(len, frames60)) - cpu["ref_bytes_60s"]) / cpu["ref_bytes_60s"]
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * nsamples / (elapsed / args.steps) / 1e6
@@ -190,11 +240,15 @@ def main():
                        "frames_per_gpu": nframes, "wide_samples_per_gpu": nsamples, "parallelism": "frame ranges x%d" % world,
                        "compressed_bytes_per_gpu": total_bytes, "ratio": round(total_bytes / (nsamples * 4), 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "fa_%s_kernel" % dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(KERNEL_OF_STAGE.get(dom, dom), args.minutes),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer VALU-bound kernel: ~(order+5) lane-ops per sample per LPC candidate; see DESIGN.md"},
         }
+        if decode is not None:
+            line["decode"] = decode
+        if size_delta is not None:
+            line["size_delta_vs_ref"] = round(size_delta, 6)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

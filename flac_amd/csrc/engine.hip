@@ -250,10 +250,11 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	// one arena for all per-batch arrays
 	const size_t G = (size_t)max_frames * c.nsig, F = max_frames;
 	const size_t qrows = p.max_lpc_order ? p.max_lpc_order : 1u;
+	c.cand_stride = (uint32_t)((1u + qrows + 3u) & ~(size_t)3u);
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
-		o_ncand = take(G * 4), o_chdr = take((size_t)c.max_cand * G * 4), o_cq = take((size_t)c.max_cand * qrows * G * 4),
+		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4),
 		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
 	e->arena_bytes = off;
@@ -262,7 +263,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	uint8_t *b = (uint8_t*)e->arena;
 	FaWork &w = e->work;
 	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
-	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_chdr); w.cand_q = (int32_t*)(b + o_cq);
+	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg);
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
 

@@ -35,6 +35,7 @@ struct FaCfg {
 	uint32_t num_apod;
 	uint32_t lag;             // max_lpc_order + 1
 	uint32_t max_cand;        // candidate slots per signal
+	uint32_t cand_stride;     // dwords per candidate record: header + coefficients, rounded to a multiple of 4
 	uint32_t k_limit;         // 15, or 31 when stream bps > 16 (stream_encoder.c:3200)
 	uint32_t wide_fixed;      // 64-bit fixed-predictor error sums (stream_encoder.c:894)
 	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
@@ -88,8 +89,10 @@ struct FaWork {
 	float    *autoc;       // [num_apod][lag][G]
 	// model
 	uint32_t *ncand;       // [G]
-	uint32_t *cand_hdr;    // [max_cand][G]
-	int32_t  *cand_q;      // [max_cand][max_lpc_order][G]
+	// candidate records, one signal's records contiguous: [G][max_cand][cand_stride] dwords, each record
+	// = header word then the coefficients; cand_q points one dword past cand_hdr so that both index alike
+	uint32_t *cand_hdr;
+	int32_t  *cand_q;
 	// search
 	FaWinner *winner;      // [G]
 	// pack
@@ -135,6 +138,9 @@ __device__ __forceinline__ int32_t fa_signal(const void *pcm, const FaCfg &c, ui
 	}
 	return fa_pcm(pcm, c.pcm_format, c.channels, wide, s);
 }
+
+// dword index of the record of candidate `slot` of signal g (header at cand_hdr[idx], coefficient j at cand_q[idx + j])
+__device__ __forceinline__ size_t fa_cand_idx(const FaCfg &c, uint32_t g, uint32_t slot) { return ((size_t)g * c.max_cand + slot) * c.cand_stride; }
 
 __device__ __forceinline__ uint32_t fa_ilog2(uint32_t v) { return 31u - (uint32_t)__clz((int)v); } // v > 0
 #endif

@@ -21,9 +21,9 @@
 #define FA_LN2 0.69314718055994530942
 
 struct CandWriter {
-	uint32_t *hdr; int32_t *q; uint32_t G, g, qrows, n, max_cand;
-	__device__ __forceinline__ void emit(uint32_t h) { if(n < max_cand) hdr[(size_t)n * G + g] = h; n++; }
-	__device__ __forceinline__ void coef(uint32_t j, int32_t v) { if(n < max_cand) q[((size_t)n * qrows + j) * G + g] = v; }
+	uint32_t *hdr; int32_t *q; uint32_t stride, n, max_cand;   // hdr / q already offset to this signal's records
+	__device__ __forceinline__ void emit(uint32_t h) { if(n < max_cand) hdr[(size_t)n * stride] = h; n++; }
+	__device__ __forceinline__ void coef(uint32_t j, int32_t v) { if(n < max_cand) q[(size_t)n * stride + j] = v; }
 };
 
 // lpc.c:1336-1351
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 	const uint32_t wasted = w.wasted[g];
 	const uint32_t bps = c.bps - wasted + ((c.midside && s == 3u) ? 1u : 0u);
 
-	CandWriter cw; cw.hdr = w.cand_hdr; cw.q = w.cand_q; cw.G = c.G; cw.g = g; cw.qrows = c.max_lpc_order ? c.max_lpc_order : 1u; cw.n = 0; cw.max_cand = c.max_cand;
+	CandWriter cw; cw.hdr = w.cand_hdr + fa_cand_idx(c, g, 0); cw.q = w.cand_q + fa_cand_idx(c, g, 0); cw.stride = c.cand_stride; cw.n = 0; cw.max_cand = c.max_cand;
 
 	const bool constant = (!c.disable_constant) && w.is_const[g];
 	if(n >= FA_MAX_FIXED_ORDER && !constant) {

@@ -92,10 +92,10 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 		for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * prow + (t % parts0)] = 0;
 		for(uint32_t t = tid; t < gn * 16u; t += 256) lbits[t] = 0;
 		// candidate headers and coefficients of this group: one parallel fetch into LDS
-		for(uint32_t t = tid; t < gn; t += 256) chdr[t] = w.cand_hdr[(size_t)(cb + t) * c.G + g];
+		for(uint32_t t = tid; t < gn; t += 256) chdr[t] = w.cand_hdr[fa_cand_idx(c, g, (cb + t))];
 		for(uint32_t t = tid; t < gn * HIST; t += 256) {
 			const uint32_t ci = t / HIST, j = t - ci * HIST;
-			cq[t] = (j < qrows) ? w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] : 0;
+			cq[t] = (j < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + j] : 0;
 		}
 		__syncthreads();
 		if(tid < gn) {
@@ -155,12 +155,12 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 					int32_t pred;
 					if(wide) {
 						long long acc = 0;
-						for(uint32_t j = 0; j < order; j++) acc += (long long)w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] * (long long)xs[xs_idx((int32_t)(i - 1u - j))];
+						for(uint32_t j = 0; j < order; j++) acc += (long long)w.cand_q[fa_cand_idx(c, g, (cb + ci)) + j] * (long long)xs[xs_idx((int32_t)(i - 1u - j))];
 						pred = (int32_t)(acc >> shift);
 					}
 					else {
 						uint32_t acc = 0;
-						for(uint32_t j = 0; j < order; j++) acc += (uint32_t)w.cand_q[((size_t)(cb + ci) * qrows + j) * c.G + g] * (uint32_t)xs[xs_idx((int32_t)(i - 1u - j))];
+						for(uint32_t j = 0; j < order; j++) acc += (uint32_t)w.cand_q[fa_cand_idx(c, g, (cb + ci)) + j] * (uint32_t)xs[xs_idx((int32_t)(i - 1u - j))];
 						pred = (int32_t)acc >> shift;
 					}
 					r = (int32_t)((uint32_t)xs[xs_idx((int32_t)i)] - (uint32_t)pred);
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	FaWinner *win = &w.winner[g];
 	if(use_cand) {
 		const uint32_t bc = sh.best_cand;
-		const uint32_t hdr = w.cand_hdr[(size_t)bc * c.G + g];
+		const uint32_t hdr = w.cand_hdr[fa_cand_idx(c, g, bc)];
 		const uint32_t order = FA_CAND_ORDER(hdr), po = sh.best_po;
 		// Rice parameters spread to the finest configured order: entry e belongs to partition e >> (emax - po),
 		// so that the pack stage can index them by sample position alone
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 		bool big = false;
 		for(uint32_t pe = tid; pe < parts_cap; pe += 256) { const uint8_t k = best_k[pe >> (emax - po)]; win->k[pe] = k; big |= (k >= 15); }
 		if(big) atomicOr(&sh.rice2, 1u);
-		if(tid < FLACAMD_MAX_LPC_ORDER) win->q[tid] = (FA_CAND_KIND(hdr) && tid < order) ? w.cand_q[((size_t)bc * qrows + tid) * c.G + g] : 0;
+		if(tid < FLACAMD_MAX_LPC_ORDER) win->q[tid] = (FA_CAND_KIND(hdr) && tid < order) ? w.cand_q[fa_cand_idx(c, g, bc) + tid] : 0;
 		__syncthreads();
 		if(tid == 0) {
 			const uint32_t ty = FA_CAND_KIND(hdr) ? FA_SUB_LPC : FA_SUB_FIXED;
@@ -323,7 +323,7 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 	return (b + 15u) & ~(size_t)15u;
 }
 
-extern "C" int fa_search_fast_ok(const FaCfg *c);
+extern "C" int fa_search_fast_ok(const void *pcm, const FaCfg *c);
 extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, uint32_t frames, hipStream_t st);
 
 extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st)
@@ -331,7 +331,7 @@ extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *
 	// full-length frames of common streams go to the register-resident kernel; a short last
 	// frame and everything else to the general one
 	uint32_t fast_frames = 0;
-	if(fa_search_fast_ok(c)) fast_frames = (c->last_n == c->N) ? c->F : c->F - 1u;
+	if(fa_search_fast_ok(pcm, c)) fast_frames = (c->last_n == c->N) ? c->F : c->F - 1u;
 	fa_launch_search_fast(pcm, c, w, cg, sum64, fast_frames, st);
 	const uint32_t g0 = fast_frames * c->nsig, rest = c->G - g0;
 	if(rest == 0) return;

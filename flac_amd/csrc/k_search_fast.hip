@@ -66,13 +66,12 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 	}
 }
 
-// PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample.
+// PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample;
+// PK = 2: the same from 32-bit samples (what process_interleaved hands over).
 // LIGHT = 1: no candidate of the stream can need the 64-bit prediction sum or more than 24-bit
 // samples (decided on the host), so those paths and their registers are compiled out.
-// Capped at 80 registers (6 waves per SIMD: three workgroups per CU): the few spills cost less
-// than the third workgroup gains in hiding the load and evaluation latencies (measured).
 template<typename SUM, int PK, int LIGHT>
-__global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCfg &c, const FaWork &w, uint32_t cg)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 
@@ -104,39 +103,7 @@ __global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const voi
 	uint32_t *cpo = cinfo + cg;                                        // [cg] best partition order | rice2 << 8
 	uint8_t *kbuf = (uint8_t*)(cpo + cg);                              // [cg][64] Rice parameters at the candidate's best order
 
-	// ---- this thread's samples i0 - HIST .. i0 + SF_CH - 1, issued before anything waits
-	int32_t xw[SF_W];
 	const bool active = i0 < n;
-	if(PK) {
-		uint32_t raw[SF_W];
-#pragma unroll
-		for(int j = 0; j < SF_W / 4; j++) {
-			const int32_t rel = (int32_t)i0 - HIST + 4 * j;
-			uint4 v = make_uint4(0u, 0u, 0u, 0u);
-			if(active && rel >= 0) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
-			raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
-		}
-		// signal = (ca * left + cb * right) >> (cs + wasted): L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058)
-		const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
-		const uint32_t shv = wasted + (s == 2u ? 1u : 0u);
-#pragma unroll
-		for(int j = 0; j < SF_W; j++) {
-			const int32_t l = (int32_t)(int16_t)(raw[j] & 0xffffu), r = (int32_t)raw[j] >> 16;
-			xw[j] = (ca * l + cb * r) >> shv;
-		}
-	}
-	else {
-#pragma unroll
-		for(int j = 0; j < SF_W; j++) {
-			const int32_t rel = (int32_t)i0 - HIST + j;
-			xw[j] = (active && rel >= 0) ? (fa_signal(pcm, c, s, base + (uint32_t)rel) >> wasted) : 0;
-		}
-	}
-
-	// samples biased into unsigned order for the |a - b| instruction
-	uint32_t xb[SF_CH];
-#pragma unroll
-	for(int j = 0; j < SF_CH; j++) xb[j] = (uint32_t)xw[HIST + j] ^ 0x80000000u;
 	// samples and coefficients fit 16 bits: two taps per instruction (the side channel of a
 	// 16-bit stream has 17 bits and stays on the one-tap path)
 	const bool use_dot2 = bps <= 16u && !(c.debug & 0x8000u);
@@ -159,20 +126,65 @@ __global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const voi
 		// candidate headers and coefficients of this group: one parallel fetch into LDS, for every
 		// slot of the group whether used or not, so that the loads do not wait for the candidate count
 		for(uint32_t t = tid; t < cg * (HIST / 2 + 1u); t += SF_THREADS) {
-			if(t < cg) chdr[t] = (cb + t < c.max_cand) ? w.cand_hdr[(size_t)(cb + t) * c.G + g] : 0u;
+			if(t < cg) chdr[t] = (cb + t < c.max_cand) ? w.cand_hdr[fa_cand_idx(c, g, (cb + t))] : 0u;
 			else {
 				const uint32_t tt = t - cg, ci = tt / (HIST / 2), m = tt - ci * (HIST / 2);
 				const bool ok = cb + ci < c.max_cand;
 				// rows at and above the candidate's order are not written by the model stage: read them as zero
-				const uint32_t ord = ok ? FA_CAND_ORDER(w.cand_hdr[(size_t)(cb + ci) * c.G + g]) : 0u;
-				int32_t q0 = (ok && 2u * m < qrows) ? w.cand_q[((size_t)(cb + ci) * qrows + 2u * m) * c.G + g] : 0;
-				int32_t q1 = (ok && 2u * m + 1u < qrows) ? w.cand_q[((size_t)(cb + ci) * qrows + 2u * m + 1u) * c.G + g] : 0;
+				const uint32_t ord = ok ? FA_CAND_ORDER(w.cand_hdr[fa_cand_idx(c, g, (cb + ci))]) : 0u;
+				int32_t q0 = (ok && 2u * m < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + 2u * m] : 0;
+				int32_t q1 = (ok && 2u * m + 1u < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + 2u * m + 1u] : 0;
 				if(2u * m >= ord) q0 = 0;
 				if(2u * m + 1u >= ord) q1 = 0;
 				cq[ci * HIST + 2u * m] = q0; cq[ci * HIST + 2u * m + 1u] = q1;
 				cqp[tt] = pack_lo16(q0, q1);
 			}
 		}
+		// ---- this thread's samples i0 - HIST .. i0 + SF_CH - 1, fetched anew for every candidate group (there is
+		// one group unless a precision search multiplies the candidates) so that they do not occupy
+		// registers during the evaluation phase; issued before anything waits
+		int32_t xw[SF_W];
+		if(PK == 1) {
+			uint32_t raw[SF_W];
+#pragma unroll
+			for(int j = 0; j < SF_W / 4; j++) {
+				const int32_t rel = (int32_t)i0 - HIST + 4 * j;
+				uint4 v = make_uint4(0u, 0u, 0u, 0u);
+				if(active && rel >= 0) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
+				raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
+			}
+			// signal = (ca * left + cb * right) >> (cs + wasted): L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058)
+			const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
+			const uint32_t shv = wasted + (s == 2u ? 1u : 0u);
+#pragma unroll
+			for(int j = 0; j < SF_W; j++) {
+				const int32_t l = (int32_t)(int16_t)(raw[j] & 0xffffu), r = (int32_t)raw[j] >> 16;
+				xw[j] = (ca * l + cb * r) >> shv;
+			}
+		}
+		else {
+			// 32-bit stereo: two wide samples per 16-byte load
+			int32_t l[SF_W], r[SF_W];
+#pragma unroll
+			for(int j = 0; j < SF_W / 2; j++) {
+				const int32_t rel = (int32_t)i0 - HIST + 2 * j;
+				uint4 v = make_uint4(0u, 0u, 0u, 0u);
+				if(active && rel >= 0) v = *(const uint4*)((const int32_t*)pcm + (base + (uint32_t)rel) * 2u);
+				l[2*j] = (int32_t)v.x; r[2*j] = (int32_t)v.y; l[2*j+1] = (int32_t)v.z; r[2*j+1] = (int32_t)v.w;
+			}
+#pragma unroll
+			for(int j = 0; j < SF_W; j++) {
+				int32_t v;
+				if(c.midside) v = s == 0u ? l[j] : s == 1u ? r[j] : s == 2u ? ((int32_t)((uint32_t)l[j] + (uint32_t)r[j]) >> 1) : (int32_t)((uint32_t)l[j] - (uint32_t)r[j]);
+				else v = s == 0u ? l[j] : r[j];
+				xw[j] = v >> wasted;
+			}
+		}
+
+		// samples biased into unsigned order for the |a - b| instruction
+		uint32_t xb[SF_CH];
+#pragma unroll
+		for(int j = 0; j < SF_CH; j++) xb[j] = (uint32_t)xw[HIST + j] ^ 0x80000000u;
 		__syncthreads();
 		SF_STAMP(1);
 		if(tid < gn) {
@@ -219,7 +231,14 @@ __global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const voi
 					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
 					accT = 0; accH = 0; accM = 0;
-					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, by_residual);
+					if(FA_CAND_KIND(hdr) == 0) {
+						// the differences need 4 samples of history: unpack them from the pairs rather than keep
+						// the unpacked window alive through the loop
+						int32_t xf[SF_W];
+#pragma unroll
+						for(int j = 0; j < SF_W; j++) xf[j] = j >= HIST - 4 ? (int32_t)(int16_t)(xp[j] & 0xffffu) : 0;
+						fixed_each_dispatch(order, xf, by_residual);
+					}
 					else if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
 					else {
 						uint32_t qp[HIST / 2];
@@ -368,6 +387,14 @@ __global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const voi
 #undef SF_STAMP
 }
 
+// The kernels are capped at 80 registers (6 waves per SIMD: three workgroups per
+// CU): their few spills cost less than the third workgroup gains in hiding the load and
+// evaluation latencies (measured).  Other sample layouts take the general kernel.
+template<typename SUM, int PK, int LIGHT>
+__global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+{
+	sf_body<SUM, PK, LIGHT>(pcm, c, w, cg);
+}
 extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum64)
 {
 	(void)c;
@@ -380,10 +407,11 @@ extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum6
 	return (b + 15u) & ~(size_t)15u;
 }
 
-// Full-length blocks that fit 512 x 8 samples, with finest partitions that are multiples of
+// Stereo streams, full-length blocks that fit 512 x 8 samples, with finest partitions that are multiples of
 // 8 samples, at most 64 of them, and predictor orders within the register window.
-extern "C" int fa_search_fast_ok(const FaCfg *c)
+extern "C" int fa_search_fast_ok(const void *pcm, const FaCfg *c)
 {
+	if(c->channels != 2u || ((uintptr_t)pcm % 16u) != 0) return 0;   // stereo, rows of 4 (16-bit) or 2 (32-bit) wide samples per 16-byte load
 	if(c->N > (uint32_t)(SF_THREADS * SF_CH) || (c->N % SF_CH) != 0 || c->max_lpc_order > (uint32_t)HIST || (c->debug & 0x800u)) return 0;
 	uint32_t tz = 0;
 	while(!((c->N >> tz) & 1u)) tz++;
@@ -397,7 +425,7 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 	if(frames == 0) return;
 	const size_t lds = fa_search_fast_lds_bytes(c, cg, sum64);
 	const dim3 grid(frames * c->nsig), block(SF_THREADS);
-	const bool pk = c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && ((uintptr_t)pcm % 16u) == 0;
+	const int pk = c->pcm_format == FLACAMD_PCM_S16 ? 1 : 2;
 	// can any candidate take the 64-bit prediction sum (stream_encoder.c:3597-3603: bps + precision + ilog2(order) > 32)
 	// or carry more than 24-bit samples?
 	uint32_t lg = 0;
@@ -408,8 +436,9 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 #define SF_LAUNCH(SUMT, PKV, LV) do { \
 		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV, LV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
-	if(sum64) { if(pk) SF_LAUNCH(unsigned long long, 1, 0); else SF_LAUNCH(unsigned long long, 0, 0); }
-	else if(light) { if(pk) SF_LAUNCH(uint32_t, 1, 1); else SF_LAUNCH(uint32_t, 0, 1); }
-	else { if(pk) SF_LAUNCH(uint32_t, 1, 0); else SF_LAUNCH(uint32_t, 0, 0); }
+	if(sum64) { if(pk == 1) SF_LAUNCH(unsigned long long, 1, 0); else SF_LAUNCH(unsigned long long, 2, 0); }
+	else if(light) { if(pk == 1) SF_LAUNCH(uint32_t, 1, 1); else SF_LAUNCH(uint32_t, 2, 1); }
+	else { if(pk == 1) SF_LAUNCH(uint32_t, 1, 0); else SF_LAUNCH(uint32_t, 2, 0); }
 #undef SF_LAUNCH
+
 }

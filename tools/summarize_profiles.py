@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/profile_round.sh into the committed summaries:
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_per_kernel.csv and profiles/<tag>_pmc_summary.json
+(HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, both in KiB per dispatch as rocprofv3 reports them;
+the doubling is the measured gfx950 behaviour for wide coalesced reads)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_round")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+minutes = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0].strip()
+
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    print("kernel stats:", stats[0], len(rows) - 1, "kernels")
+
+per = defaultdict(lambda: defaultdict(list))
+for d in glob.glob(os.path.join(src, "pmc_*")):
+    if not os.path.isdir(d):
+        continue
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+counters = sorted({c for k in per.values() for c in k})
+with open(os.path.join(ROOT, "profiles", tag + "_pmc_per_kernel.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "dispatches"] + ["mean_" + c for c in counters])
+    for k, cs in sorted(per.items()):
+        n = max(len(v) for v in cs.values())
+        w.writerow([k, n] + [("%.1f" % (sum(cs[c]) / len(cs[c])) if c in cs else "") for c in counters])
+summary = {"minutes": minutes, "note": "per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+for k, cs in per.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        e = {"fetch_size_kib": round(fe, 1), "write_size_kib": round(wr, 1), "hbm_bytes_per_launch": int((2 * fe + wr) * 1024)}
+        if "SQ_BUSY_CYCLES" in cs and "SQ_ACTIVE_INST_VALU" in cs:
+            e["valu_active_over_busy"] = round(sum(cs["SQ_ACTIVE_INST_VALU"]) / max(sum(cs["SQ_BUSY_CYCLES"]), 1.0), 4)
+        summary["kernels"][k] = e
+json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True))
