@@ -27,6 +27,7 @@
 
 struct FdCfg {
 	uint32_t channels, bps, max_bs, max_frames;
+	uint32_t ws_stride;   // dwords between the rows of ws: max_bs plus a pad that staggers the rows over the memory channels
 	uint64_t nbytes;
 	uint32_t nscan_wg;
 	uint32_t crc_seg_bytes;
@@ -42,7 +43,7 @@ struct FdWork {
 	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bits 4..7 assignment (0..3)
 	uint32_t *cand_bs;      // [max_frames]
 	uint64_t *cand_num;     // [max_frames] frame or sample number from the header
-	int32_t  *ws;           // [max_frames][channels][max_bs] subframe outputs before decorrelation
+	int32_t  *ws;           // [max_frames][channels][ws_stride] subframe outputs before decorrelation
 	uint32_t *frame_of;     // [max_frames] candidate index of the r-th accepted frame
 	uint64_t *sample_off;   // [max_frames] first wide sample of the r-th accepted frame
 	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
@@ -162,19 +163,39 @@ __global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w
 // ---- speculative decode, one lane per candidate
 
 struct BitReader {
+	// The stream is consumed through a 64-bit window refilled 32 bits at a time from a 16-byte chunk
+	// held in registers; the chunk after it is always already requested, so a lane never waits a
+	// full memory round trip in the middle of a token (a lane owns its frame: nobody else fetches
+	// these bytes for it).
 	const uint8_t *b; uint64_t nbytes, widx, bitpos; unsigned long long buf; uint32_t avail; bool err;
-	__device__ __forceinline__ uint32_t load_word(uint64_t wi) const
+	uint4 cur, nxt; uint64_t cur_chunk;   // chunk index (16-byte units) held in cur; nxt holds cur_chunk + 1
+	__device__ __forceinline__ uint4 load_chunk(uint64_t ck) const
 	{
-		const uint64_t off = wi * 4u;
-		if(off + 4u <= nbytes) return __builtin_bswap32(*(const uint32_t*)(b + off));
-		uint32_t v = 0;
-		for(uint32_t k = 0; k < 4; k++) v = (v << 8) | (off + k < nbytes ? (uint32_t)b[off + k] : 0u);
-		return v;
+		const uint64_t off = ck * 16u;
+		if(off + 16u <= nbytes) return *(const uint4*)(b + off);
+		uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;   // tail of the buffer: byte by byte, never past the end
+#pragma unroll
+		for(uint32_t k = 0; k < 4u; k++) {
+			if(off + k < nbytes) v0 |= (uint32_t)b[off + k] << (8u * k);
+			if(off + 4u + k < nbytes) v1 |= (uint32_t)b[off + 4u + k] << (8u * k);
+			if(off + 8u + k < nbytes) v2 |= (uint32_t)b[off + 8u + k] << (8u * k);
+			if(off + 12u + k < nbytes) v3 |= (uint32_t)b[off + 12u + k] << (8u * k);
+		}
+		return make_uint4(v0, v1, v2, v3);
+	}
+	__device__ __forceinline__ uint32_t load_word(uint64_t wi)
+	{
+		const uint64_t ck = wi >> 2;
+		if(ck != cur_chunk) { cur = nxt; cur_chunk = ck; nxt = load_chunk(ck + 1u); }
+		const uint32_t sel = (uint32_t)wi & 3u;
+		const uint32_t v = sel == 0u ? cur.x : sel == 1u ? cur.y : sel == 2u ? cur.z : cur.w;
+		return __builtin_bswap32(v);
 	}
 	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)load_word(widx++) << (32u - avail); avail += 32u; } }
 	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos)
 	{
 		b = base; nbytes = nb; widx = pos >> 2; buf = 0; avail = 0; err = false; bitpos = (pos >> 2) * 32u;
+		cur_chunk = widx >> 2; cur = load_chunk(cur_chunk); nxt = load_chunk(cur_chunk + 1u);
 		refill();
 		const uint32_t skip = (uint32_t)(pos & 3u) * 8u;
 		buf <<= skip; avail -= skip; bitpos += skip;
@@ -214,6 +235,7 @@ struct BitReader {
 };
 
 #define FD_RING 32u
+#define FD_REGORD 12
 
 __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
@@ -236,7 +258,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 	for(uint32_t ch = 0; ch < h.channels && ok; ch++) {
 		uint32_t bps = h.bps;
 		if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
-		int32_t *out = w.ws + ((size_t)ci * c.channels + ch) * c.max_bs;
+		int32_t *out = w.ws + ((size_t)ci * c.channels + ch) * c.ws_stride;
 		uint32_t head = br.read(8);
 		if(head & 0x80u) { ok = false; break; }                                           // :2481
 		uint32_t wasted = 0;
@@ -248,13 +270,22 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			const bool lpc = head >= 64;
 			const uint32_t order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
 			if(order > n || (!lpc && order > 4u)) { ok = false; break; }
-			int32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0; // fixed predictor history: x[i-1..i-4]
+			// Prediction state.  Orders up to FD_REGORD keep coefficients and history in registers
+			// (unused taps have zero coefficients; a fixed predictor is the order-k predictor with
+			// binomial coefficients and no shift, identical modulo 2^32); larger orders use the
+			// per-lane LDS columns.
+			int32_t qr[FD_REGORD], hr[FD_REGORD];
+#pragma unroll
+			for(int j = 0; j < FD_REGORD; j++) { qr[j] = 0; hr[j] = 0; }
+			const bool in_regs = order <= (uint32_t)FD_REGORD;
 			uint32_t hp = 0;
 			for(uint32_t i = 0; i < order; i++) {
 				const int32_t v = br.read_signed(bps);
 				out[i] = v << wasted;
 				s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
-				h3 = h2; h2 = h1; h1 = h0; h0 = v;
+#pragma unroll
+				for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
+				hr[0] = v;
 			}
 			uint32_t prec = 0, shift = 0, wide = 0;
 			if(lpc) {
@@ -265,7 +296,17 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 				if(sh < 0) { ok = false; break; }     // never produced by the reference encoder (lpc.c:225-260); shifting by a negative count is undefined there
 				shift = (uint32_t)sh;
 				for(uint32_t j = 0; j < order; j++) s_q[j][lane] = br.read_signed(prec);
+				// back through the lane's own LDS column with fixed indices (an indexed register array
+				// would be placed in scratch memory)
+#pragma unroll
+				for(int t = 0; t < FD_REGORD; t++) qr[t] = ((uint32_t)t < order) ? s_q[t][lane] : 0;
 				wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
+			}
+			else { // fixed.c:395-435
+				if(order == 1) { qr[0] = 1; }
+				else if(order == 2) { qr[0] = 2; qr[1] = -1; }
+				else if(order == 3) { qr[0] = 3; qr[1] = -3; qr[2] = 1; }
+				else if(order == 4) { qr[0] = 4; qr[1] = -6; qr[2] = 4; qr[3] = -1; }
 			}
 			const uint32_t method = br.read(2);
 			if(method > 1u) { ok = false; break; }                                       // :2580
@@ -289,16 +330,27 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 					}
 					else r = br.read_signed(raw);
 					int32_t x;
-					if(lpc) {
+					if(in_regs) {
+						if(wide) {
+							long long sum = 0;
+#pragma unroll
+							for(int j = 0; j < FD_REGORD; j++) sum += (long long)qr[j] * (long long)hr[j];
+							x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift));
+						}
+						else {
+							uint32_t sum = 0;
+#pragma unroll
+							for(int j = 0; j < FD_REGORD; j++) sum += (uint32_t)qr[j] * (uint32_t)hr[j];
+							x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift));
+						}
+#pragma unroll
+						for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
+						hr[0] = x;
+					}
+					else {
 						if(wide) { long long sum = 0; for(uint32_t j = 0; j < order; j++) sum += (long long)s_q[j][lane] * (long long)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift)); }
 						else { uint32_t sum = 0; for(uint32_t j = 0; j < order; j++) sum += (uint32_t)s_q[j][lane] * (uint32_t)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift)); }
 						s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
-					}
-					else {
-						const uint32_t a = (uint32_t)h0, bb = (uint32_t)h1, cc = (uint32_t)h2, d = (uint32_t)h3, rr = (uint32_t)r;
-						const uint32_t v = order == 0 ? rr : order == 1 ? rr + a : order == 2 ? rr + 2u*a - bb : order == 3 ? rr + 3u*a - 3u*bb + cc : rr + 4u*a - 6u*bb + 4u*cc - d;
-						x = (int32_t)v;
-						h3 = h2; h2 = h1; h1 = h0; h0 = x;
 					}
 					out[i] = (int32_t)((uint32_t)x << wasted);
 					if(br.err) { ok = false; break; }
@@ -409,10 +461,10 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 	const uint32_t ci = w.frame_of[r];
 	const uint32_t n = w.cand_bs[ci], assignment = (w.cand_info[ci] >> 4) & 15u;
 	const uint64_t s0 = w.sample_off[r];
-	const int32_t *src = w.ws + (size_t)ci * c.channels * c.max_bs;
+	const int32_t *src = w.ws + (size_t)ci * c.channels * c.ws_stride;
 	if(c.channels == 2) {
 		for(uint32_t i = threadIdx.x; i < n; i += 256) {
-			int32_t a = src[i], b = src[c.max_bs + i];
+			int32_t a = src[i], b = src[c.ws_stride + i];
 			if(assignment == 1) b = (int32_t)((uint32_t)a - (uint32_t)b);
 			else if(assignment == 2) a = (int32_t)((uint32_t)a + (uint32_t)b);
 			else if(assignment == 3) {
@@ -427,7 +479,7 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 		const uint32_t total = n * c.channels;
 		for(uint32_t t = threadIdx.x; t < total; t += 256) {
 			const uint32_t i = t / c.channels, ch = t - i * c.channels;
-			const int32_t v = src[(size_t)ch * c.max_bs + i];
+			const int32_t v = src[(size_t)ch * c.ws_stride + i];
 			if(c.pcm_format == FLACAMD_PCM_S16) ((int16_t*)pcm)[(s0 + i) * c.channels + ch] = (int16_t)v;
 			else ((int32_t*)pcm)[(s0 + i) * c.channels + ch] = v;
 		}
@@ -465,6 +517,9 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	d->device = device; d->max_bytes = max_bytes;
 	FdCfg &c = d->cfg;
 	c.channels = channels; c.bps = bits_per_sample; c.max_bs = max_blocksize; c.max_frames = max_frames;
+	// one lane per frame writes its own row, 64 rows at a time: rows a power of two apart would all land on one
+	// memory channel, so every row is pushed 256 bytes further than the last
+	c.ws_stride = ((max_blocksize + 63u) & ~63u) + 64u;
 	// longest possible frame: header + per channel (head + verbatim-sized body with one spare bit per sample) + footer
 	const size_t max_frame_bytes = 16 + (size_t)channels * (((size_t)max_blocksize * (bits_per_sample + 2) + 7) / 8 + 64) + 2;
 	c.crc_seg_bytes = (uint32_t)((max_frame_bytes + 63) / 64);
@@ -473,7 +528,7 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = fd_align(off + bytes); return o; };
 	const size_t o_cnt = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
-		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * max_blocksize * 4),
+		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * c.ws_stride * 4),
 		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(1024);
 	d->arena_bytes = off;
 	hipError_t he = hipMalloc(&d->arena, off);
@@ -509,7 +564,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	if(!d || !d_bytes || !d_pcm || nbytes == 0 || nbytes > d->max_bytes) return FLACAMD_E_INVALID_ARGUMENT;
 	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
 	if(pcm_format == FLACAMD_PCM_S16 && d->cfg.bps > 16) return FLACAMD_E_INVALID_ARGUMENT;
-	if(((uintptr_t)d_bytes & 3u) != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(((uintptr_t)d_bytes & 15u) != 0) return FLACAMD_E_INVALID_ARGUMENT;   // the bit reader fetches 16-byte chunks
 	hipStream_t st = (hipStream_t)stream;
 	FD_TRY(hipSetDevice(d->device));
 	FdCfg c = d->cfg;

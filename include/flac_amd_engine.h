@@ -148,7 +148,7 @@ int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_t channels,
 	uint32_t max_blocksize, uint32_t max_frames, size_t max_bytes);
 void flacamd_decoder_destroy(flacamd_decoder *d);
 
-/* Decode a byte range of frames held in device memory (no metadata): finds the frame
+/* Decode a byte range of frames held in device memory (no metadata; d_bytes 16-byte aligned): finds the frame
  * boundaries (sync code + header CRC-8 + frame CRC-16, stream_decoder.c:1947-2145),
  * decodes every frame in parallel and writes interleaved PCM (pcm_format) to d_pcm in
  * stream order.  h_info[0]=frames, [1]=wide samples, [2]=first frame number,
