@@ -233,6 +233,26 @@ static FLAC__StreamEncoderWriteStatus file_write(const FLAC__StreamEncoder *e, c
 
 static void put_be(uint8_t *p, uint64_t v, unsigned nbytes) { unsigned i; for(i = 0; i < nbytes; i++) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
 
+/* The head of a finished stream in one piece: "fLaC", STREAMINFO with every field filled in, and the
+ * empty VORBIS_COMMENT that carries the vendor string (what a seekable client ends up with after
+ * update_metadata_, :2521-2620).  For callers of the batch engine that assemble files themselves. */
+size_t flacamd_write_stream_head(uint8_t out[FLACAMD_STREAM_HEAD_BYTES], uint32_t blocksize, uint32_t min_framesize, uint32_t max_framesize,
+	uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample, uint64_t total_samples, const uint8_t md5[16])
+{
+	const size_t vlen = strlen(VENDOR_STRING);
+	uint8_t *b = out;
+	memcpy(b, "fLaC", 4); b += 4;
+	b[0] = 0; put_be(b + 1, 34, 3);
+	put_be(b + 4, blocksize, 2); put_be(b + 6, blocksize, 2); put_be(b + 8, min_framesize, 3); put_be(b + 11, max_framesize, 3);
+	put_be(b + 14, ((uint64_t)sample_rate << 44) | ((uint64_t)(channels - 1) << 41) | ((uint64_t)(bits_per_sample - 1) << 36) | (total_samples & 0xFFFFFFFFFull), 8);
+	if(md5) memcpy(b + 22, md5, 16); else memset(b + 22, 0, 16);
+	b += 38;
+	b[0] = 0x80 | 4; put_be(b + 1, 8 + vlen, 3);
+	b[4] = (uint8_t)vlen; b[5] = b[6] = b[7] = 0; memcpy(b + 8, VENDOR_STRING, vlen); memset(b + 8 + vlen, 0, 4);
+	b += 4 + 8 + vlen;
+	return (size_t)(b - out);
+}
+
 static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC__StreamEncoderWriteCallback wcb, FLAC__StreamEncoderSeekCallback scb,
 	FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
 {

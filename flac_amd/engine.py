@@ -80,6 +80,9 @@ def lib():
         L.flacamd_decoder_destroy.restype = None
         L.flacamd_decode_device.argtypes = [vp, vp, sz, vp, C.c_int, u64, vp, vp]
         L.flacamd_decode_host.argtypes = [vp, vp, sz, vp, C.c_int, u64, vp]
+        L.flacamd_write_stream_head.argtypes = [vp, u32, u32, u32, u32, u32, u32, u64, vp]
+        L.flacamd_write_stream_head.restype = sz
+        L.flacamd_decoder_frame_table.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         L.flacamd_strerror.argtypes = [C.c_int]
         L.flacamd_strerror.restype = C.c_char_p
         L.flacamd_last_error.restype = C.c_char_p
@@ -242,3 +245,11 @@ def md5_device(d_pcm_ptr, fmt, channels, bits_per_sample, offsets, device=0, str
     out = np.zeros((n, 16), dtype=np.uint8)
     _check(lib().flacamd_md5_device(device, d_pcm_ptr, fmt, channels, bits_per_sample, off.ctypes.data, n, out.ctypes.data, stream), "flacamd_md5_device")
     return [bytes(r) for r in out]
+
+
+def stream_head(blocksize, min_framesize, max_framesize, sample_rate, channels, bits_per_sample, total_samples, md5):
+    """'fLaC' + STREAMINFO + VORBIS_COMMENT of a finished stream (flacamd_write_stream_head)."""
+    out = np.zeros(86, dtype=np.uint8)
+    m = np.frombuffer(bytes(md5), dtype=np.uint8).copy()
+    n = lib().flacamd_write_stream_head(out.ctypes.data, blocksize, min_framesize, max_framesize, sample_rate, channels, bits_per_sample, total_samples, m.ctypes.data)
+    return bytes(out[:n])

@@ -165,6 +165,13 @@ int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, size_t nbyte
 int flacamd_decoder_frame_table(flacamd_decoder *d, uint32_t nframes, uint64_t *h_sample_off, uint32_t *h_blocksize,
 	uint64_t *h_number, uint32_t *h_assignment, uint64_t *h_byte_pos, uint64_t *h_byte_end);
 
+/* "fLaC" + STREAMINFO + the empty VORBIS_COMMENT with the reference's vendor string, as the reference
+ * leaves them in a finished file (stream_encoder.c:1034-1106 written at init, :2521-2620 patched at
+ * finish): for callers that assemble streams from engine output themselves.  Returns the byte count. */
+#define FLACAMD_STREAM_HEAD_BYTES 86
+size_t flacamd_write_stream_head(uint8_t out[FLACAMD_STREAM_HEAD_BYTES], uint32_t blocksize, uint32_t min_framesize, uint32_t max_framesize,
+	uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample, uint64_t total_samples, const uint8_t md5[16]);
+
 const char *flacamd_strerror(int code);
 /* Text of the last failing HIP call on this thread ("" if none). */
 const char *flacamd_last_error(void);

@@ -152,3 +152,27 @@ def test_full_size_stream_properties(gpu_engine):
         nf, dec = ob.oracle_decode(blob[offs[lo]:offs[hi]], 2, 16, (hi - lo) * 4096)
         assert nf == hi - lo
         assert np.array_equal(dec, pcm[lo * 4096:min(hi * 4096, n)].astype(np.int32))
+
+
+def test_eight_channel_24bit_exhaustive_precision_search(gpu_engine):
+    """flac -8 -e -p on 24-bit / 96 kHz / 8 channels: 64-bit prediction sums, 132 LPC candidates per
+    channel in several candidate groups; 4 s against the oracle frame by frame, then a longer run
+    through the device decoder."""
+    from flac_amd import synth
+    kw = dict(level=8, do_exhaustive_model_search=1, do_qlp_coeff_prec_search=1)
+    pcm = synth.multichannel_24(4.0, rate=96000, channels=8, seed=4321)
+    fp, _ = ob.make_params(8, 24, 96000, **kw)
+    want = ob.oracle_encode(fp, pcm)["frames"]
+    enc, (frames, _) = _encode(gpu_engine, 8, 24, 96000, kw, pcm)
+    enc.close()
+    assert frames == want
+    long_pcm = synth.multichannel_24(20.0, rate=96000, channels=8, seed=99)
+    enc, (frames, _) = _encode(gpu_engine, 8, 24, 96000, kw, long_pcm)
+    enc.close()
+    blob = b"".join(frames)
+    dec = gpu_engine.Decoder(8, 24, 4096, len(frames) + 64, len(blob) + 64)
+    back, info = dec.decode_host(blob, len(long_pcm))
+    dec.close()
+    assert info["frames"] == len(frames) and np.array_equal(back, long_pcm)
+    ratio = len(blob) / (long_pcm.size * 3)
+    assert 0.3 < ratio < 0.95
