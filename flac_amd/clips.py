@@ -18,6 +18,7 @@ def encode_clips(clips, level=5, device=0):
     """clips: list of (pcm, bits_per_sample, sample_rate) with pcm an int array (samples, channels).
     Returns a list of bytes objects, one complete stream per clip, in input order."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     groups = {}
     for idx, (pcm, bps, rate) in enumerate(clips):
         pcm = np.asarray(pcm)
@@ -26,42 +27,60 @@ def encode_clips(clips, level=5, device=0):
         groups.setdefault((pcm.shape[1], bps, rate), []).append(idx)
     out = [None] * len(clips)
     dev = torch.device("cuda", device)
+    torch.cuda.set_device(device)
+    plans = []
+    pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(groups))))
+    # ---- phase 1: upload every group, start its MD5 launch on a stream of its own (one lane per clip:
+    # the digests take as long as the longest clip, which the encode calls below overlap)
     for (ch, bps, rate), members in groups.items():
         params = engine.make_params(ch, bps, rate, level=level)
-        probe = engine.lib()
         p2 = engine.Params.from_buffer_copy(params)
-        if probe.flacamd_params_resolve(p2) != 0:
+        if engine.lib().flacamd_params_resolve(p2) != 0:
             raise engine.EngineError(-1, "flacamd_params_resolve")
         bs = int(p2.blocksize)
         fmt, dt = (engine.PCM_S16, np.int16) if bps <= 16 else (engine.PCM_S32, np.int32)
+        item = np.dtype(dt).itemsize * ch
         lens = [clips[i][0].shape[0] for i in members]
         # every clip starts on a 16-byte boundary of the shared buffer: the vector-load kernels require it
-        align = 16 // (np.dtype(dt).itemsize * ch) if 16 % (np.dtype(dt).itemsize * ch) == 0 else 16
+        align = 16 // item if 16 % item == 0 else 16
         starts, pos = [], 0
         for n in lens:
             starts.append(pos)
             pos += -(-n // align) * align
         host = np.zeros((pos, ch), dtype=dt)
         for i, st, n in zip(members, starts, lens):
-            host[st:st + n] = np.asarray(clips[i][0]).astype(dt)
+            host[st:st + n] = clips[i][0]
         d_pcm = torch.from_numpy(host).to(dev)
-        max_frames = max(-(-n // bs) for n in lens)
-        enc = engine.Encoder(params, max_frames=max_frames, device=device)
-        cap = enc.max_output_bytes(max_frames)
-        d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-        d_fb = torch.empty(max_frames, dtype=torch.int32, device=dev)
-        # MD5 of all clips of the group in one launch: offsets are wide-sample positions
-        # (the alignment gaps between clips are hashed as streams of their own and dropped)
-        offs = []
+        offs = []   # the alignment gaps between clips are hashed as streams of their own and dropped
         for st, n in zip(starts, lens):
             offs += [st, st + n]
-        digests = engine.md5_device(d_pcm.data_ptr(), fmt, ch, bps, offs, device=device)[::2]
-        for k, (i, st, n) in enumerate(zip(members, starts, lens)):
-            nfr = -(-n // bs)
-            total = enc.encode_device(d_pcm.data_ptr() + st * ch * np.dtype(dt).itemsize, fmt, n, d_out.data_ptr(), cap, d_fb.data_ptr(), final=True, first_frame=0)
-            data = d_out[:total].cpu().numpy().tobytes()
-            sizes = d_fb[:nfr].cpu().numpy()
-            head = engine.stream_head(bs, int(sizes.min()), int(sizes.max()), rate, ch, bps, n, digests[k])
-            out[i] = head + data
+        side = torch.cuda.Stream(device=dev)
+        fut = pool.submit(engine.md5_device, d_pcm.data_ptr(), fmt, ch, bps, offs, device, side.cuda_stream)
+        plans.append((ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side))
+    # ---- phase 2: one engine call per clip on the resident buffers; outputs stay on the device
+    results = []
+    for ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side in plans:
+        nfr = [-(-n // bs) for n in lens]
+        enc = engine.Encoder(params, max_frames=max(nfr), device=device)
+        caps = [enc.max_output_bytes(f) for f in nfr]
+        d_out = torch.empty(sum(caps), dtype=torch.uint8, device=dev)
+        d_fb = torch.empty(sum(nfr), dtype=torch.int32, device=dev)
+        totals, o_off, f_off = [], 0, 0
+        for st, n, f, cap in zip(starts, lens, nfr, caps):
+            totals.append(enc.encode_device(d_pcm.data_ptr() + st * item, fmt, n, d_out.data_ptr() + o_off, cap, d_fb.data_ptr() + 4 * f_off, final=True, first_frame=0))
+            o_off += cap
+            f_off += f
         enc.close()
+        results.append((d_out.cpu().numpy(), d_fb.cpu().numpy(), totals, caps, nfr))
+    # ---- phase 3: digests, stream heads, assembly
+    for (ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side), (h_out, h_fb, totals, caps, nfr) in zip(plans, results):
+        digests = fut.result()[::2]
+        o_off = f_off = 0
+        for k, i in enumerate(members):
+            sizes = h_fb[f_off:f_off + nfr[k]]
+            head = engine.stream_head(bs, int(sizes.min()), int(sizes.max()), rate, ch, bps, lens[k], digests[k])
+            out[i] = head + h_out[o_off:o_off + totals[k]].tobytes()
+            o_off += caps[k]
+            f_off += nfr[k]
+    pool.shutdown()
     return out

@@ -37,6 +37,42 @@ __device__ void md5_block(uint32_t (&h)[4], const uint32_t (&m)[16])
 	h[0] += a; h[1] += b; h[2] += c; h[3] += d;
 }
 
+// value t of the flattened interleaved stream
+__device__ __forceinline__ uint32_t md5_val(const void *pcm, uint32_t fmt, uint64_t t)
+{
+	return fmt == FLACAMD_PCM_S16 ? (uint32_t)(int32_t)((const int16_t*)pcm)[t] : (uint32_t)((const int32_t*)pcm)[t];
+}
+
+// 64 consecutive values = NB whole 64-byte blocks, packed with compile-time byte positions
+template<int NB>
+__device__ __forceinline__ void md5_super_block(uint32_t (&h)[4], const void *pcm, uint32_t fmt, uint64_t t0)
+{
+	uint32_t mm[NB * 16];
+	if(NB == 1) {
+#pragma unroll
+		for(int j = 0; j < 16; j++) mm[j] = (md5_val(pcm, fmt, t0 + 4 * j) & 0xffu) | ((md5_val(pcm, fmt, t0 + 4 * j + 1) & 0xffu) << 8) | ((md5_val(pcm, fmt, t0 + 4 * j + 2) & 0xffu) << 16) | (md5_val(pcm, fmt, t0 + 4 * j + 3) << 24);
+	}
+	else if(NB == 2) {
+#pragma unroll
+		for(int j = 0; j < 32; j++) mm[j] = (md5_val(pcm, fmt, t0 + 2 * j) & 0xffffu) | (md5_val(pcm, fmt, t0 + 2 * j + 1) << 16);
+	}
+	else {
+#pragma unroll
+		for(int j = 0; j < 16; j++) { // four 3-byte samples -> three words
+			const uint32_t a = md5_val(pcm, fmt, t0 + 4 * j) & 0xffffffu, b = md5_val(pcm, fmt, t0 + 4 * j + 1) & 0xffffffu,
+			               c = md5_val(pcm, fmt, t0 + 4 * j + 2) & 0xffffffu, d = md5_val(pcm, fmt, t0 + 4 * j + 3) & 0xffffffu;
+			mm[3 * j] = a | (b << 24); mm[3 * j + 1] = (b >> 8) | (c << 16); mm[3 * j + 2] = (c >> 16) | (d << 8);
+		}
+	}
+#pragma unroll
+	for(int blk = 0; blk < NB; blk++) {
+		uint32_t m[16];
+#pragma unroll
+		for(int i = 0; i < 16; i++) m[i] = mm[blk * 16 + i];
+		md5_block(h, m);
+	}
+}
+
 __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
 	const uint64_t *__restrict__ offsets, uint32_t nstreams, uint8_t *__restrict__ digests)
 {
@@ -45,13 +81,23 @@ __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm
 	const uint64_t s0 = offsets[sidx], s1 = offsets[sidx + 1];
 	const uint32_t nb = (bps + 7u) / 8u;
 	uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+	// bulk: 64 values at a time are a whole number of blocks
+	uint64_t t = s0 * channels;
+	const uint64_t tend = s1 * channels;
+	uint64_t total = 0;
+	for(; t + 64u <= tend; t += 64u) {
+		if(nb == 1u) md5_super_block<1>(h, pcm, fmt, t);
+		else if(nb == 2u) md5_super_block<2>(h, pcm, fmt, t);
+		else md5_super_block<3>(h, pcm, fmt, t);
+		total += 64u * nb;
+	}
+	// tail and padding: byte by byte
 	uint32_t m[16];
 #pragma unroll
 	for(int i = 0; i < 16; i++) m[i] = 0;
 	uint32_t fill = 0;            // bytes in the current block
-	uint64_t total = 0;
 	auto push = [&](uint32_t byte) {
-		// static register indexing: the word index is resolved by a switch the compiler turns into selects
+		// static register indexing: the word index is resolved by selects
 		const uint32_t wi = fill >> 2, sh = (fill & 3u) * 8u;
 #pragma unroll
 		for(int i = 0; i < 16; i++) if((uint32_t)i == wi) m[i] |= byte << sh;
@@ -63,11 +109,10 @@ __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm
 			fill = 0;
 		}
 	};
-	for(uint64_t i = s0; i < s1; i++)
-		for(uint32_t ch = 0; ch < channels; ch++) {
-			const uint32_t v = (uint32_t)fa_pcm(pcm, fmt, channels, i, ch);
-			for(uint32_t k = 0; k < nb; k++) push((v >> (8u * k)) & 0xffu);
-		}
+	for(; t < tend; t++) {
+		const uint32_t v = md5_val(pcm, fmt, t);
+		for(uint32_t k = 0; k < nb; k++) push((v >> (8u * k)) & 0xffu);
+	}
 	const uint64_t bits = total * 8u;
 	push(0x80u);
 	while(fill != 56u) push(0u);
