@@ -21,9 +21,13 @@ def short(name):
     return name.split("(")[0].strip()
 
 
+VALU_PEAK = 1024 * 2.4e9 / 2.0   # wave-instructions per second: 1024 SIMDs, one full-rate wave64 VALU op per 2 cycles at 2.4 GHz
+avg_ns = {}
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     rows = list(csv.reader(open(stats[0])))
+    for r in csv.DictReader(open(stats[0])):
+        avg_ns[short(r["Name"])] = float(r["AverageNs"])
     with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f).writerows(rows)
     print("kernel stats:", stats[0], len(rows) - 1, "kernels")
@@ -42,13 +46,18 @@ with open(os.path.join(ROOT, "profiles", tag + "_pmc_per_kernel.csv"), "w", newl
     for k, cs in sorted(per.items()):
         n = max(len(v) for v in cs.values())
         w.writerow([k, n] + [("%.1f" % (sum(cs[c]) / len(cs[c])) if c in cs else "") for c in counters])
-summary = {"minutes": minutes, "note": "per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
+summary = {"minutes": minutes, "note": "per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; valu_issue_frac = SQ_INSTS_VALU / time / (1024 SIMDs * 2.4 GHz / 2)", "kernels": {}}
 for k, cs in per.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
         e = {"fetch_size_kib": round(fe, 1), "write_size_kib": round(wr, 1), "hbm_bytes_per_launch": int((2 * fe + wr) * 1024)}
-        if "SQ_BUSY_CYCLES" in cs and "SQ_ACTIVE_INST_VALU" in cs:
-            e["valu_active_over_busy"] = round(sum(cs["SQ_ACTIVE_INST_VALU"]) / max(sum(cs["SQ_BUSY_CYCLES"]), 1.0), 4)
+        if "SQ_INSTS_VALU" in cs and k in avg_ns:
+            insts = sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"])
+            e["avg_ms"] = round(avg_ns[k] / 1e6, 4)
+            e["valu_wave_insts_per_launch"] = int(insts)
+            # share of the chip's full-rate vector issue slots the kernel fills (half-rate integer ops
+            # such as v_mad_i32_i24 / v_dot2 / v_sad occupy two slots but count once: a lower bound on busy)
+            e["valu_issue_frac"] = round(insts / (avg_ns[k] * 1e-9) / VALU_PEAK, 4)
         summary["kernels"][k] = e
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))
