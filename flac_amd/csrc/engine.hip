@@ -185,6 +185,7 @@ struct flacamd_encoder {
 	uint32_t last_F, last_G;
 	int timing;
 	hipEvent_t ev[7];
+	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the autocorrelation stage runs beside the prep stage
 	float last_ms[6];
 	int have_timing;
 };
@@ -255,7 +256,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
-		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4),
+		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
 		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
@@ -264,7 +265,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	FaWork &w = e->work;
 	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
-	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg);
+	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
@@ -298,7 +299,9 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		free(hw);
 		if(he != hipSuccess) { rc = hip_fail(he, "hipMemcpy(window)"); hipFree(e->arena); free(e); return rc; }
 	}
-	for(int i = 0; i < 7; i++) hipEventCreate(&e->ev[i]);
+	for(int i = 0; i < 7; i++) (void)hipEventCreate(&e->ev[i]);
+	if(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess
+		|| hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { flacamd_encoder_destroy(e); return FLACAMD_E_DEVICE; }
 	*out = e;
 	return FLACAMD_OK;
 }
@@ -307,7 +310,10 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 {
 	if(!e) return;
 	hipSetDevice(e->device);
-	for(int i = 0; i < 7; i++) if(e->ev[i]) hipEventDestroy(e->ev[i]);
+	for(int i = 0; i < 7; i++) if(e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+	if(e->side) (void)hipStreamDestroy(e->side);
+	if(e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+	if(e->ev_join) (void)hipEventDestroy(e->ev_join);
 	if(e->arena) hipFree(e->arena);
 	if(e->d_pcm_stage) hipFree(e->d_pcm_stage);
 	if(e->d_out_stage) hipFree(e->d_out_stage);
@@ -348,11 +354,21 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 
 	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
 	const bool tm = e->timing != 0;
-	if(tm) hipEventRecord(e->ev[0], st);
+	if(tm) (void)hipEventRecord(e->ev[0], st);
+	// prep and autocorrelation read the same PCM and do not depend on each other (the model stage
+	// rescales the sums by the wasted bits): side by side on two streams, joined before the model
+	const bool fork = c.max_lpc_order > 0 && !(c.debug & 0x10000u);
+	if(fork) {
+		HIP_TRY(hipEventRecord(e->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+		fa_launch_autoc(d_pcm, &c, &e->work, e->side);
+		HIP_TRY(hipEventRecord(e->ev_join, e->side));
+	}
 	fa_launch_prep(d_pcm, &c, &e->work, st);
-	if(tm) hipEventRecord(e->ev[1], st);
-	if(c.max_lpc_order > 0) fa_launch_autoc(d_pcm, &c, &e->work, st);
-	if(tm) hipEventRecord(e->ev[2], st);
+	if(tm) (void)hipEventRecord(e->ev[1], st);
+	if(fork) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+	else if(c.max_lpc_order > 0) fa_launch_autoc(d_pcm, &c, &e->work, st);
+	if(tm) (void)hipEventRecord(e->ev[2], st);
 	fa_launch_model(&c, &e->work, st);
 	if(tm) hipEventRecord(e->ev[3], st);
 	fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);

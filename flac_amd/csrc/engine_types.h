@@ -79,6 +79,16 @@ struct FaWinner {
 #define FA_WIN_WASTED(h) (((h) >> 23) & 31u)
 #define FA_WIN_WIDE(h)   (((h) >> 28) & 1u)
 
+// What the pack stage needs to know about one frame, gathered in one place by the assignment
+// kernel so that the pack workgroup fetches it in a single round of loads: per coded subframe the
+// winner's header word, bits per sample and signal index, its coefficients and its Rice parameters
+// (spread to the finest configured partition order).
+struct FaPackRec {
+	uint32_t hdr0[2], sbps[2], sig[2], assignment, pad;
+	int32_t  q[2][12];
+	uint8_t  k[2][FA_MAX_PARTS];
+};
+
 // Device workspace pointers of one encoder.
 struct FaWork {
 	// prep
@@ -99,6 +109,7 @@ struct FaWork {
 	uint8_t  *slots;       // [F][slot_bytes]
 	uint32_t *frame_bytes; // [F]
 	uint32_t *assignment;  // [F]
+	FaPackRec *packrec;    // [F] (mono / stereo fast path)
 	uint32_t *status;      // [1] nonzero = some frame overflowed its slot
 	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
 	const float *window;   // [num_apod][N]

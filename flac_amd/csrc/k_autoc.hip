@@ -12,9 +12,15 @@
 //
 // Each lane streams its own signal straight from the interleaved PCM into registers,
 // 16 samples per step with the next step's loads already in flight (the 4 signals of a
-// frame share the same bytes through L1/L2), applies the wasted-bit shift and the window
+// frame share the same bytes through L1/L2), applies the window
 // (wave-uniform index: scalar loads) and keeps the last `lag` windowed samples in a
-// register delay line.  No LDS.  Cost: 2*lag + ~8 VALU instructions per sample per lane.
+// register delay line.  No LDS.
+//
+// The reference removes a signal's wasted (all-zero low) bits before this stage.  Here the
+// unshifted signal is used, so that this kernel does not depend on the wasted-bit scan and can
+// run beside it: every sample is the shifted one times 2^w, int-to-float conversion, products
+// and sums all scale by exact powers of two (nothing overflows below 2^62), so each sum comes
+// out as 4^w times the reference's, bit for bit, and the model stage divides it back out.  Cost: 2*lag + ~8 VALU instructions per sample per lane.
 #include "engine_types.h"
 
 #define AC_STEP 16
@@ -39,12 +45,11 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const uint32_t f = gg >> 2, s = gg & 3u;
 	const uint32_t n = fa_frame_len(c, f);
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
-	const uint32_t wasted = w.wasted[gg];
 	const uint32_t f0 = (blockIdx.x * 64u) >> 2;
 	const uint32_t nloop = (f0 + 1 == c.F) ? c.last_n : c.N;
-	// signal = (ca * left + cb * right) >> (cs + wasted): L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058)
+	// signal = (ca * left + cb * right) >> cs: L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), wasted bits left in
 	const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
-	const uint32_t sh = wasted + (s == 2u ? 1u : 0u);
+	const uint32_t sh = s == 2u ? 1u : 0u;
 
 	auto load16 = [&](uint32_t i0) {
 		Raw16 r;
@@ -108,7 +113,6 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 	const uint32_t f = gg / c.nsig, s = gg - f * c.nsig;
 	const uint32_t n = fa_frame_len(c, f);
 	const uint64_t base = (uint64_t)f * c.N;
-	const uint32_t wasted = w.wasted[gg];
 	// lanes are in frame order, so if the first lane sits in the last frame all lanes do
 	const uint32_t f0 = (blockIdx.x * 64u) / c.nsig;
 	const uint32_t nloop = (f0 + 1 == c.F) ? c.last_n : c.N;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 #pragma unroll
 			for(int j = 0; j < 4; j++) {
 				const uint32_t i = i0 + (uint32_t)j;
-				const float d = __fmul_rn((float)(cur[j] >> wasted), win[i < c.N ? i : c.N - 1u]); // lpc.c:60
+				const float d = __fmul_rn((float)cur[j], win[i < c.N ? i : c.N - 1u]); // lpc.c:60
 #pragma unroll
 				for(int k = LAG - 1; k > 0; k--) hist[k] = hist[k-1];
 				hist[0] = d;

@@ -192,7 +192,15 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 				for(uint32_t a = 0; a < c.num_apod; a++) {
 					float autoc[MAXORD + 1];
 #pragma unroll
-					for(int l = 0; l <= MAXORD; l++) autoc[l] = ((uint32_t)l < c.lag) ? w.autoc[((size_t)a * c.lag + l) * c.G + g] : 0.0f;
+					for(int l = 0; l <= MAXORD; l++) {
+						autoc[l] = 0.0f;
+						if((uint32_t)l < c.lag) {
+							// the autocorrelation stage ran on the unshifted signal: exactly 4^wasted too large
+							float *slot = &w.autoc[((size_t)a * c.lag + l) * c.G + g];
+							autoc[l] = ldexpf(*slot, -2 * (int)wasted);
+							if(wasted) *slot = autoc[l];
+						}
+					}
 					if(autoc[0] == 0.0f) continue;
 					double lpc[MAXORD], errs[MAXORD], err = (double)autoc[0];
 #pragma unroll

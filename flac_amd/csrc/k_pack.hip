@@ -507,8 +507,32 @@ __device__ __forceinline__ void pf_load4(const void *__restrict__ pcm, uint32_t 
 	}
 }
 
+// One wave per frame: the channel assignment and the pack record (see FaPackRec).
 template<int NSUB>
-__global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+__global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
+{
+	const uint32_t f = blockIdx.x, lane = threadIdx.x;
+	const uint32_t a = fa_assignment(c, w, f);
+	FaPackRec *rec = &w.packrec[f];
+#pragma unroll
+	for(int sc = 0; sc < NSUB; sc++) {
+		uint32_t sig = (uint32_t)sc;
+		if(c.midside) { // stream_encoder.c:3096-3115
+			if(a == 1) sig = sc == 0 ? 0u : 3u;
+			else if(a == 2) sig = sc == 0 ? 3u : 1u;
+			else if(a == 3) sig = sc == 0 ? 2u : 3u;
+		}
+		const FaWinner *win = &w.winner[f * c.nsig + sig];
+		if(lane == 0) { rec->hdr0[sc] = win->hdr[0]; rec->sbps[sc] = win->hdr[2]; rec->sig[sc] = sig; }
+		if(lane < 12u) rec->q[sc][lane] = win->q[lane];
+		((uint32_t*)rec->k[sc])[lane] = ((const uint32_t*)win->k)[lane];   // 256 bytes
+	}
+	if(lane == 0) { rec->assignment = a; w.assignment[f] = a; }
+}
+
+// Capped at 80 registers: three workgroups per CU (1.30 -> 1.03 ms per hour of audio; a fourth costs more in spills than it hides).
+template<int NSUB>
+__global__ void __launch_bounds__(PF_THREADS, 6) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
@@ -527,27 +551,27 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 	if(tid < 512u) ((uint32_t*)sh.crc4)[tid] = ((const uint32_t*)w.crc16_table4)[tid];
 	if(tid == 0) sh.crc_acc = 0;
 
-	// ---- wave-uniform decisions: assignment, the winner of every subframe
-	const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)fa_assignment(c, w, f));
-	if(tid == 0) w.assignment[f] = a;
+	// ---- wave-uniform decisions, all from the frame's pack record: one round of loads
+	const FaPackRec *rec = &w.packrec[f];
+	const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec->assignment);
 	SubDesc d[NSUB];
+	int32_t qsel[NSUB][HIST];
+	uint32_t kpre[NSUB];
 #pragma unroll
 	for(int sc = 0; sc < NSUB; sc++) {
-		uint32_t sig = (uint32_t)sc;
-		if(c.midside) { // stream_encoder.c:3096-3115
-			if(a == 1) sig = sc == 0 ? 0u : 3u;
-			else if(a == 2) sig = sc == 0 ? 3u : 1u;
-			else if(a == 3) sig = sc == 0 ? 2u : 3u;
-		}
-		const uint32_t g = f * c.nsig + sig;
-		const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.winner[g].hdr[0]);
+		const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec->hdr0[sc]);
 		SubDesc &s = d[sc];
-		s.sig = sig; s.g = g;
-		s.sbps = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.winner[g].hdr[2]);
+		s.sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec->sig[sc]); s.g = f * c.nsig + s.sig;
+		s.sbps = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec->sbps[sc]);
 		s.type = FA_WIN_TYPE(h0); s.order = FA_WIN_ORDER(h0); s.prec = FA_WIN_PREC(h0); s.shift = FA_WIN_SHIFT(h0); s.po = FA_WIN_PO(h0);
 		s.rice2 = FA_WIN_RICE2(h0); s.wasted = FA_WIN_WASTED(h0); s.wide = FA_WIN_WIDE(h0);
 		s.nwarm = s.type == FA_SUB_CONSTANT ? 1u : s.type >= FA_SUB_FIXED ? s.order : 0u;
 		s.head_bits = 8u + s.wasted + s.nwarm * s.sbps + (s.type == FA_SUB_LPC ? 9u + s.order * s.prec : 0u) + (s.type >= FA_SUB_FIXED ? 6u : 0u);
+#pragma unroll
+		for(int j = 0; j < HIST; j++) qsel[sc][j] = __builtin_amdgcn_readfirstlane(rec->q[sc][j]);
+		// the Rice parameters are stored spread to the finest configured order: indexed by position, not by the winner's order
+		const uint32_t e = i0 / (c.N >> kspread);
+		kpre[sc] = rec->k[sc][e < FA_MAX_PARTS ? e : FA_MAX_PARTS - 1u];
 	}
 	const FrameHdrFields hf = fa_frame_header_fields(c, n, c.first_frame + f);
 
@@ -585,7 +609,7 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 			const uint32_t dps = n >> s.po;
 			if(s.po && (dps % PF_CH)) bad = true;
 			const uint32_t p = s.po ? i0 / dps : 0u;
-			if(s.type >= FA_SUB_FIXED) kk[sc] = w.winner[s.g].k[p << (kspread - s.po)];
+			if(s.type >= FA_SUB_FIXED) kk[sc] = kpre[sc];
 			int32_t xw[PF_W];
 #pragma unroll
 			for(int j = 0; j < PF_W; j++) {
@@ -611,7 +635,7 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 				else {
 					int32_t qc[HIST];
 #pragma unroll
-					for(int j = 0; j < HIST; j++) qc[j] = __builtin_amdgcn_readfirstlane(w.winner[s.g].q[j]);
+					for(int j = 0; j < HIST; j++) qc[j] = qsel[sc][j];
 					if(s.wide) lpc_each_dispatch<MAC_WIDE>(s.order, xw, qc, s.shift, keep);
 					else if(s.sbps <= 24) lpc_each_dispatch<MAC_I24>(s.order, xw, qc, s.shift, keep);
 					else lpc_each_dispatch<MAC_I32>(s.order, xw, qc, s.shift, keep);
@@ -707,7 +731,7 @@ __global__ void __launch_bounds__(PF_THREADS) fa_pack_fast_kernel(const void *__
 			else if(lpc && t < 2u + wtok + s.nwarm + s.order) {
 				const uint32_t j = t - 2u - wtok - s.nwarm;
 				pos += 8u + s.wasted + s.nwarm * s.sbps + 9u + j * s.prec;
-				v = (uint32_t)w.winner[s.g].q[j] & ((1u << s.prec) - 1u); nb = s.prec;
+				v = (uint32_t)rec->q[hi ? NSUB - 1 : 0][j] & ((1u << s.prec) - 1u); nb = s.prec;
 			}
 			else { pos += s.head_bits - 6u; v = (s.rice2 << 4) | s.po; nb = 6; }
 			put_shared(bitbuf, pos, v, nb);
@@ -859,6 +883,8 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 	if(fa_pack_fast_ok(pcm, c)) {
 		const uint32_t words = fa_pack_fast_words(c);
 		const size_t lds = ((size_t)words * 4u + 15u) & ~(size_t)15u;
+		if(c->channels == 2) hipLaunchKernelGGL(fa_assign_kernel<2>, dim3(c->F), dim3(64), 0, st, *c, *w);
+		else hipLaunchKernelGGL(fa_assign_kernel<1>, dim3(c->F), dim3(64), 0, st, *c, *w);
 		if(c->channels == 2) {
 			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 			hipLaunchKernelGGL(fa_pack_fast_kernel<2>, dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
