@@ -2,13 +2,13 @@
 // replaced in the reference and for the general kernel).
 //
 // Applies to full-length blocks of at most 4096 samples whose finest partitions are whole
-// multiples of 8 samples, to partition orders up to 6 and predictor orders up to HIST: the
-// common streams.  One 512-thread workgroup per (frame, signal), 8 samples + HIST of history
+// multiples of 16 samples, to partition orders up to 6 and predictor orders up to HIST: the
+// common streams.  One 256-thread workgroup per (frame, signal), 16 samples + HIST of history
 // per thread, read straight from the interleaved PCM into registers (left/right/mid/side are
 // formed from the same words): no LDS copy of the signal.  Every global load the workgroup
 // needs is issued before the first barrier.
 //
-//   multiply-add phase  every thread evaluates all candidates on its 8 samples; 16-bit signals
+//   multiply-add phase  every thread evaluates all candidates on its 16 samples; 16-bit signals
 //                       take two taps per instruction (v_dot2_i32_i16 on packed pairs) and
 //                       |x - pred| accumulates in one instruction (v_sad_u32); one LDS atomic per
 //                       thread and candidate into the 64 finest-partition sums
@@ -25,8 +25,8 @@
 #include "residual.h"
 #include "wave_ops.h"
 
-#define SF_THREADS 512
-#define SF_CH 8
+#define SF_THREADS 256
+#define SF_CH 16
 #define SF_W (HIST + SF_CH)
 #define SF_WAVES (SF_THREADS / 64)
 #define SF_PARTS 64u     // finest partitions one wave prices: partition orders up to 6
@@ -387,11 +387,13 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 #undef SF_STAMP
 }
 
-// The kernels are capped at 80 registers (6 waves per SIMD: three workgroups per
-// CU): their few spills cost less than the third workgroup gains in hiding the load and
-// evaluation latencies (measured).  Other sample layouts take the general kernel.
+// 256 threads x 16 samples, capped at 128 registers: four independent workgroups per CU (one wave per
+// SIMD each) overlap each other's load, multiply-add and evaluation phases.  Measured alternatives on the
+// headline workload: 512 x 8 samples at 2 / 3 workgroups per CU 4.9 / 4.3 ms per hour of audio, this shape
+// 3.8 ms; tighter caps (5 or 6 workgroups) gain 2 % and spill 80-100 bytes per lane; evaluating three
+// candidates side by side in a wave spills and gains nothing.  Other sample layouts take the general kernel.
 template<typename SUM, int PK, int LIGHT>
-__global__ void __launch_bounds__(SF_THREADS, 6) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__global__ void __launch_bounds__(SF_THREADS, 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
 	sf_body<SUM, PK, LIGHT>(pcm, c, w, cg);
 }
@@ -407,8 +409,8 @@ extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum6
 	return (b + 15u) & ~(size_t)15u;
 }
 
-// Stereo streams, full-length blocks that fit 512 x 8 samples, with finest partitions that are multiples of
-// 8 samples, at most 64 of them, and predictor orders within the register window.
+// Stereo streams, full-length blocks that fit 256 x 16 samples, with finest partitions that are multiples of
+// 16 samples, at most 64 of them, and predictor orders within the register window.
 extern "C" int fa_search_fast_ok(const void *pcm, const FaCfg *c)
 {
 	if(c->channels != 2u || ((uintptr_t)pcm % 16u) != 0) return 0;   // stereo, rows of 4 (16-bit) or 2 (32-bit) wide samples per 16-byte load

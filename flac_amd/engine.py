@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflacamd.so")
+LIB_PATH = os.environ.get("FLACAMD_LIB") or os.path.join(_HERE, "libflacamd.so")   # the override is a development aid for comparing builds
 
 PCM_S32, PCM_S16 = 0, 1
 
