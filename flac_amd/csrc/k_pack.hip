@@ -435,9 +435,9 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 
 // ---- fast path: mono / stereo streams, blocksize <= 4096, predictor orders <= HIST ----------
 //
-// One 512-thread workgroup per frame, 8 samples per thread, every subframe of the frame in
+// One 256-thread workgroup per frame, 16 samples per thread, every subframe of the frame in
 // the same pass.  Nothing depends on a previous step's global load: the winners' headers are
-// read first (wave-uniform), then every thread fetches its 8 + HIST wide samples straight
+// read first (wave-uniform), then every thread fetches its 16 + HIST wide samples straight
 // from the interleaved PCM into registers (no LDS copy of the signal) together with its Rice
 // parameter, forms the signals it needs (left/right/mid/side) from the same registers,
 // computes residual tokens and their bit lengths, and ONE workgroup scan over (bits of
@@ -445,8 +445,8 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 // (type, warm-up samples, coefficients) are written token-parallel by the first wave.  The
 // whole frame is assembled in LDS and flushed once: coalesced word stores, CRC-16 per thread
 // segment folded with x^(32 w) multipliers.  Four barriers per frame.
-#define PF_THREADS 512
-#define PF_CH 8
+#define PF_THREADS 256
+#define PF_CH 16
 #define PF_W (HIST + PF_CH)
 
 struct PackFastShared {
@@ -530,9 +530,10 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 	if(lane == 0) { rec->assignment = a; w.assignment[f] = a; }
 }
 
-// Capped at 80 registers: three workgroups per CU (1.30 -> 1.03 ms per hour of audio; a fourth costs more in spills than it hides).
+// 256 threads x 16 samples capped at 128 registers: four workgroups per CU, 0.96 ms per hour of audio (512 x 8 at two /
+// three workgroups per CU: 1.30 / 1.03 ms; tighter caps spill more than the extra workgroups hide).
 template<int NSUB>
-__global__ void __launch_bounds__(PF_THREADS, 6) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+__global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(PF_THREADS, 6) fa_pack_fast_kernel(const void 
 	const uint32_t kspread = c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER;
 
 	for(uint32_t i = tid; i < bitbuf_words; i += PF_THREADS) bitbuf[i] = 0;
-	if(tid < 512u) ((uint32_t*)sh.crc4)[tid] = ((const uint32_t*)w.crc16_table4)[tid];
+	for(uint32_t i = tid; i < 512u; i += PF_THREADS) ((uint32_t*)sh.crc4)[i] = ((const uint32_t*)w.crc16_table4)[i];
 	if(tid == 0) sh.crc_acc = 0;
 
 	// ---- wave-uniform decisions, all from the frame's pack record: one round of loads
@@ -863,8 +864,8 @@ extern "C" size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out)
 	return ((size_t)xs_words_for(c->N) * 4u + (size_t)words * 4u + 15u) & ~(size_t)15u;
 }
 
-// the fast kernel applies to mono / stereo streams whose blocks fit 512 x 8 samples, whose
-// partitions are whole multiples of a thread's 8 samples and whose predictors fit the register window
+// the fast kernel applies to mono / stereo streams whose blocks fit 256 x 16 samples, whose
+// partitions are whole multiples of a thread's 16 samples and whose predictors fit the register window
 static bool fa_pack_fast_ok(const void *pcm, const FaCfg *c)
 {
 	return c->channels <= 2u && c->N <= (uint32_t)(PF_THREADS * PF_CH) && c->N % ((uint32_t)PF_CH << c->max_po) == 0 && c->max_lpc_order <= (uint32_t)HIST
