@@ -30,6 +30,7 @@ const char * const FLAC__StreamEncoderInitStatusString[] = { /* :470-485 */
 	"FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA", "FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED" };
 
 #include "host_md5.h"
+#include "metadata_blocks.h"
 
 /* ---- the object */
 struct FLAC__StreamEncoder {
@@ -54,12 +55,25 @@ struct FLAC__StreamEncoder {
 	uint8_t *out; size_t out_cap; uint32_t *frame_bytes;
 	uint32_t last_assignment;
 	uint8_t *md5_scratch;
+	/* client metadata blocks (:1711-1741: the array is ours, the blocks are the client's) and seek table tracking (:2458-2485) */
+	FLAC__StreamMetadata **metadata; unsigned num_metadata;
+	FLAC__StreamMetadata_SeekTable *seek_table; unsigned first_seekpoint_to_check;
+	FLAC__uint64 seektable_offset;
+	/* verify mode (:984-1017): device decoder, its output, what the reference keeps in verify.error_stats */
+	flacamd_decoder *vdec; int32_t *vpcm;
+	FLAC__StreamDecoderState vstate;
+	struct verify_stats { FLAC__uint64 absolute_sample; unsigned frame_number, channel, sample; FLAC__int32 expected, got; } vstats;
+	struct { int armed; FLAC__uint64 absolute_sample; unsigned channel; FLAC__int32 mask; } sample_fault;
+	struct { int armed; unsigned frame_number, byte_index, mask; } frame_fault;
 };
 
 static void set_defaults(FLAC__StreamEncoder *e) /* set_defaults_, :2107-2160 */
 {
 	const int device = e->device; const unsigned batch = e->batch_frames;
+	const struct verify_stats keep = e->vstats; /* the reference only clears these at init (:1012-1017) */
+	free(e->metadata);
 	memset(e, 0, sizeof *e);
+	e->vstats = keep; e->vstate = FLAC__STREAM_DECODER_UNINITIALIZED; /* what the finished verify decoder reports (:1351) */
 	e->device = device; e->batch_frames = batch ? batch : 1024u;
 	e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
 	e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1;
@@ -77,6 +91,8 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 static void free_buffers(FLAC__StreamEncoder *e)
 {
 	if(e->engine) { flacamd_encoder_destroy(e->engine); e->engine = 0; }
+	if(e->vdec) { flacamd_decoder_destroy(e->vdec); e->vdec = 0; }
+	free(e->vpcm); e->vpcm = 0;
 	free(e->queue); e->queue = 0; free(e->out); e->out = 0; free(e->frame_bytes); e->frame_bytes = 0; free(e->md5_scratch); e->md5_scratch = 0;
 }
 
@@ -86,6 +102,7 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *e)
 	/* :601-638: delete finishes without emitting the pending block */
 	if(e->file && e->file != stdout) fclose(e->file);
 	free_buffers(e);
+	free(e->metadata);
 	free(e);
 }
 
@@ -112,13 +129,7 @@ SETTER(set_do_md5, FLAC__bool, e->do_md5 = value)
 SETTER(set_do_escape_coding, FLAC__bool, (void)value; e->do_escape_coding = 0)
 SETTER(set_rice_parameter_search_dist, unsigned, (void)value; e->rice_parameter_search_dist = 0)
 
-FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *e, FLAC__bool value)
-{
-	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
-	if(value) return 0; /* verify mode is not provided: refuse rather than pretend */
-	e->verify = 0;
-	return 1;
-}
+SETTER(set_verify, FLAC__bool, e->verify = value ? 1 : 0)
 
 FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *e, unsigned value) /* :1455-1495 */
 {
@@ -130,7 +141,28 @@ FLAC__bool FLAC__stream_encoder_set_compression_level(FLAC__StreamEncoder *e, un
 FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *e, FLAC__StreamMetadata **metadata, unsigned num_blocks)
 {
 	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
-	return (metadata == 0 && num_blocks == 0) ? 1 : 0;
+	if(!metadata) num_blocks = 0;
+	free(e->metadata); e->metadata = 0; e->num_metadata = 0;
+	if(num_blocks) {
+		e->metadata = (FLAC__StreamMetadata**)malloc(sizeof(e->metadata[0]) * num_blocks);
+		if(!e->metadata) return 0;
+		memcpy(e->metadata, metadata, sizeof(e->metadata[0]) * num_blocks);
+		e->num_metadata = num_blocks;
+	}
+	return 1;
+}
+
+FLAC__bool flacamd_stream_encoder_inject_verify_fault(FLAC__StreamEncoder *e, FLAC__uint64 absolute_sample, unsigned channel, FLAC__int32 mask)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	e->sample_fault.armed = 1; e->sample_fault.absolute_sample = absolute_sample; e->sample_fault.channel = channel; e->sample_fault.mask = mask;
+	return 1;
+}
+FLAC__bool flacamd_stream_encoder_inject_frame_fault(FLAC__StreamEncoder *e, unsigned frame_number, unsigned byte_index, unsigned mask)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return 0;
+	e->frame_fault.armed = 1; e->frame_fault.frame_number = frame_number; e->frame_fault.byte_index = byte_index; e->frame_fault.mask = mask;
+	return 1;
 }
 
 FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *e, int device)
@@ -195,14 +227,42 @@ GETTER(get_min_residual_partition_order, unsigned, e->p.min_residual_partition_o
 GETTER(get_max_residual_partition_order, unsigned, e->p.max_residual_partition_order)
 GETTER(get_rice_parameter_search_dist, unsigned, e->rice_parameter_search_dist)
 GETTER(get_total_samples_estimate, FLAC__uint64, e->total_samples_estimate)
-const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) { return FLAC__StreamEncoderStateString[e->state]; }
+const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *e) /* :1799-1808 */
+{
+	return e->state != FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR ? FLAC__StreamEncoderStateString[e->state] : FLAC__StreamDecoderStateString[e->vstate];
+}
+FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *e) { return e->verify ? e->vstate : FLAC__STREAM_DECODER_UNINITIALIZED; }
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *e, FLAC__uint64 *absolute_sample, unsigned *frame_number, unsigned *channel, unsigned *sample, FLAC__int32 *expected, FLAC__int32 *got)
+{
+	if(absolute_sample) *absolute_sample = e->vstats.absolute_sample;
+	if(frame_number) *frame_number = e->vstats.frame_number;
+	if(channel) *channel = e->vstats.channel;
+	if(sample) *sample = e->vstats.sample;
+	if(expected) *expected = e->vstats.expected;
+	if(got) *got = e->vstats.got;
+}
 
 /* ---- writing: write_frame_ (:2431-2518) and write_bitbuffer_'s frame size tracking (:2423-2426) */
 static FLAC__bool emit(FLAC__StreamEncoder *e, const uint8_t *buf, size_t bytes, unsigned samples)
 {
 	FLAC__uint64 pos = 0;
 	if(e->tell_cb && e->tell_cb(e, &pos, e->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
-	if(samples == 0 && (buf[0] & 0x7f) == 0 && bytes == 38) e->streaminfo_offset = pos; /* the STREAMINFO block going by */
+	if(samples == 0) { /* :2445-2451: the STREAMINFO and the first SEEKTABLE block going by */
+		const unsigned type = buf[0] & 0x7f;
+		if(type == FLAC__METADATA_TYPE_STREAMINFO) e->streaminfo_offset = pos;
+		else if(type == FLAC__METADATA_TYPE_SEEKTABLE && e->seektable_offset == 0) e->seektable_offset = pos;
+	}
+	if(samples > 0 && e->seek_table && e->audio_offset > 0 && e->seek_table->num_points > 0) { /* :2458-2485: template points that fall into this frame */
+		/* the frame's own length: finish() shrinks the blocksize before coding the last block (:1323-1324) */
+		const FLAC__uint64 first = e->samples_written, last = first + samples - 1;
+		unsigned i;
+		for(i = e->first_seekpoint_to_check; i < e->seek_table->num_points; i++) {
+			FLAC__StreamMetadata_SeekPoint *pt = &e->seek_table->points[i];
+			if(pt->sample_number > last) break;
+			if(pt->sample_number >= first) { pt->sample_number = first; pt->stream_offset = pos - e->audio_offset; pt->frame_samples = samples; }
+			e->first_seekpoint_to_check++; /* several targets may share a frame: duplicates are removed by the sort at finish */
+		}
+	}
 	if(e->write_cb(e, buf, bytes, samples, e->current_frame_number, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return 0; }
 	e->bytes_written += bytes; e->samples_written += samples;
 	if(e->frames_written < e->current_frame_number + 1) e->frames_written = e->current_frame_number + 1;
@@ -257,7 +317,7 @@ static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC_
 	FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
 {
 	flacamd_params *p = &e->p;
-	int rc;
+	int rc, has_vorbis_comment = 0;
 	/* the checks and their order are init_stream_internal_'s (:656-766) */
 	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
 	if(!wcb || (scb && !tcb)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_CALLBACKS;
@@ -281,6 +341,46 @@ static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC_
 	rc = flacamd_params_resolve(p); /* fills the automatic precision, clips the partition orders */
 	if(rc != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; } /* legal for the reference, outside the engine's limits */
 
+	/* client metadata (:783-845): first SEEKTABLE is the one that gets filled in; one SEEKTABLE and one
+	 * VORBIS_COMMENT at most, no STREAMINFO, legal seek table / cue sheet / picture, one icon of each kind */
+	e->seek_table = 0; e->first_seekpoint_to_check = 0; e->seektable_offset = 0;
+	{
+		unsigned i; int has_seektable = 0, has_icon1 = 0, has_icon2 = 0;
+		has_vorbis_comment = 0;
+		for(i = 0; i < e->num_metadata; i++)
+			if(e->metadata[i] && e->metadata[i]->type == FLAC__METADATA_TYPE_SEEKTABLE) { e->seek_table = &e->metadata[i]->data.seek_table; break; }
+		for(i = 0; i < e->num_metadata; i++) {
+			const FLAC__StreamMetadata *m = e->metadata[i];
+			if(!m) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA; /* the reference would crash here */
+			switch(m->type) {
+			case FLAC__METADATA_TYPE_STREAMINFO: return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+			case FLAC__METADATA_TYPE_SEEKTABLE:
+				if(has_seektable || !FLAC__format_seektable_is_legal(&m->data.seek_table)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				has_seektable = 1; break;
+			case FLAC__METADATA_TYPE_VORBIS_COMMENT:
+				if(has_vorbis_comment) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				has_vorbis_comment = 1; break;
+			case FLAC__METADATA_TYPE_CUESHEET:
+				if(!FLAC__format_cuesheet_is_legal(&m->data.cue_sheet, m->data.cue_sheet.is_cd, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				break;
+			case FLAC__METADATA_TYPE_PICTURE:
+				if(!FLAC__format_picture_is_legal(&m->data.picture, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				if(m->data.picture.type == FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON_STANDARD) { /* 32x32 PNG (or a link), once */
+					if(has_icon1) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+					has_icon1 = 1;
+					if((strcmp(m->data.picture.mime_type, "image/png") && strcmp(m->data.picture.mime_type, "-->")) || m->data.picture.width != 32 || m->data.picture.height != 32)
+						return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+				}
+				else if(m->data.picture.type == FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON) {
+					if(has_icon2) return FLAC__STREAM_ENCODER_INIT_STATUS_INVALID_METADATA;
+					has_icon2 = 1;
+				}
+				break;
+			default: break;
+			}
+		}
+	}
+
 	e->state = FLAC__STREAM_ENCODER_OK;
 	e->write_cb = wcb; e->seek_cb = scb; e->tell_cb = tcb; e->metadata_cb = mcb; e->client_data = client_data;
 	e->current_frame_number = 0; e->queued = 0; e->last_assignment = 0;
@@ -295,6 +395,13 @@ static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC_
 	e->frame_bytes = (uint32_t*)malloc(sizeof(uint32_t) * e->batch_frames);
 	e->md5_scratch = (uint8_t*)malloc((size_t)65536 * 4);
 	if(!e->queue || !e->out || !e->frame_bytes || !e->md5_scratch) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	memset(&e->vstats, 0, sizeof e->vstats); /* :1012-1017 */
+	if(e->verify) { /* :984-1011: a decoder of our own; sized for a whole batch plus false sync candidates */
+		rc = flacamd_decoder_create(&e->vdec, e->device, p->channels, p->bits_per_sample, p->blocksize, 2 * e->batch_frames + 256, e->out_cap);
+		e->vpcm = (int32_t*)malloc(sizeof(int32_t) * (size_t)e->batch_frames * p->blocksize * p->channels);
+		if(rc != FLACAMD_OK || !e->vpcm) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+		e->vstate = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+	}
 
 	/* stream head: "fLaC", STREAMINFO, empty VORBIS_COMMENT carrying the vendor string (:1034-1106,
 	 * layouts stream_encoder_framing.c:50-110, :134-160) */
@@ -314,9 +421,22 @@ static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC_
 		memset(b + 22, 0, 16);
 		if(!emit(e, b, 38, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 		si->min_framesize = (1u << 24) - 1; si->total_samples = 0; /* :1075-1077 */
-		b[0] = 0x80 | 4; put_be(b + 1, 8 + vlen, 3);
-		b[4] = (uint8_t)vlen; b[5] = b[6] = b[7] = 0; memcpy(b + 8, VENDOR_STRING, vlen); memset(b + 8 + vlen, 0, 4);
-		if(!emit(e, b, 4 + 8 + vlen, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		if(!has_vorbis_comment) { /* :1089-1106 */
+			b[0] = (uint8_t)((e->num_metadata == 0 ? 0x80 : 0) | 4); put_be(b + 1, 8 + vlen, 3);
+			b[4] = (uint8_t)vlen; b[5] = b[6] = b[7] = 0; memcpy(b + 8, VENDOR_STRING, vlen); memset(b + 8 + vlen, 0, 4);
+			if(!emit(e, b, 4 + 8 + vlen, 0)) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		}
+	}
+	{ /* the client's blocks in the order given (:1108-1121) */
+		unsigned i;
+		for(i = 0; i < e->num_metadata; i++) {
+			uint8_t *img = 0; size_t len = 0; FLAC__bool ok;
+			e->metadata[i]->is_last = (i == e->num_metadata - 1);
+			if(flacamd_metadata_block_image(e->metadata[i], VENDOR_STRING, &img, &len) != 0) { e->state = FLAC__STREAM_ENCODER_FRAMING_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+			ok = emit(e, img, len, 0);
+			free(img);
+			if(!ok) return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		}
 	}
 	if(e->tell_cb && e->tell_cb(e, &e->audio_offset, e->client_data) == FLAC__STREAM_ENCODER_TELL_STATUS_ERROR) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
 	return FLAC__STREAM_ENCODER_INIT_STATUS_OK;
@@ -349,6 +469,63 @@ FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder
 	return FLAC__stream_encoder_init_FILE(e, f, pcb, client_data);
 }
 
+/* first difference between decoded and queued samples of one frame, searched channel by channel like
+ * verify_write_callback_ (:4207-4231) */
+static int frame_differs(FLAC__StreamEncoder *e, const int32_t *got, const int32_t *expected, unsigned blocksize, FLAC__uint64 first_sample)
+{
+	const unsigned ch = e->p.channels; unsigned c, i;
+	if(0 == memcmp(got, expected, sizeof(int32_t) * (size_t)blocksize * ch)) return 0;
+	for(c = 0; c < ch; c++) for(i = 0; i < blocksize; i++) if(got[(size_t)i * ch + c] != expected[(size_t)i * ch + c]) {
+		e->vstats.absolute_sample = first_sample + i; e->vstats.frame_number = (unsigned)(first_sample / blocksize);
+		e->vstats.channel = c; e->vstats.sample = i; e->vstats.expected = expected[(size_t)i * ch + c]; e->vstats.got = got[(size_t)i * ch + c];
+		return 1;
+	}
+	return 0;
+}
+
+/* Decode the batch just coded on the device and compare with the queue.  Returns the number of leading
+ * frames that verified; when that is less than nframes, *bad is the encoder state the failing frame asks for. */
+static unsigned verify_batch(FLAC__StreamEncoder *e, size_t nsamples, unsigned nframes, size_t total_bytes, FLAC__StreamEncoderState *bad)
+{
+	const unsigned N = e->p.blocksize, ch = e->p.channels;
+	const FLAC__uint64 batch_first = (FLAC__uint64)e->current_frame_number * N;
+	uint64_t info[4] = { 0, 0, 0, 0 };
+	unsigned f; size_t off = 0; int rc;
+	if(e->frame_fault.armed && e->frame_fault.frame_number >= e->current_frame_number && e->frame_fault.frame_number < e->current_frame_number + nframes) {
+		size_t o = 0; const unsigned rel = e->frame_fault.frame_number - e->current_frame_number;
+		for(f = 0; f < rel; f++) o += e->frame_bytes[f];
+		if(e->frame_fault.byte_index < e->frame_bytes[rel]) e->out[o + e->frame_fault.byte_index] ^= (uint8_t)e->frame_fault.mask;
+		e->frame_fault.armed = 0;
+	}
+	if(e->sample_fault.armed && e->sample_fault.absolute_sample >= batch_first && e->sample_fault.absolute_sample < batch_first + nsamples && e->sample_fault.channel < ch) {
+		e->queue[(size_t)(e->sample_fault.absolute_sample - batch_first) * ch + e->sample_fault.channel] ^= e->sample_fault.mask;
+		e->sample_fault.armed = 0;
+	}
+	rc = flacamd_decode_host(e->vdec, e->out, total_bytes, e->vpcm, FLACAMD_PCM_S32, nsamples, info);
+	if(rc == FLACAMD_OK && info[0] == nframes && info[1] == nsamples && info[3] == total_bytes) {
+		if(0 == memcmp(e->vpcm, e->queue, sizeof(int32_t) * nsamples * ch)) return nframes;
+		for(f = 0; f < nframes; f++) {
+			const unsigned bs = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
+			if(frame_differs(e, e->vpcm + (size_t)f * N * ch, e->queue + (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
+		}
+		return nframes;
+	}
+	/* the batch did not decode as a whole: find the frame, one at a time */
+	for(f = 0; f < nframes; f++) {
+		const unsigned bs = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
+		rc = flacamd_decode_host(e->vdec, e->out + off, e->frame_bytes[f], e->vpcm, FLACAMD_PCM_S32, bs, info);
+		if(rc != FLACAMD_OK || info[0] != 1 || info[1] != bs || info[3] != e->frame_bytes[f]) {
+			/* what verify_error_callback_ leaves behind (:4245-4250); the reference's decoder would be hunting for the next sync */
+			*bad = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; e->vstate = (rc == FLACAMD_OK || rc == FLACAMD_E_BAD_STREAM) ? FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC : FLAC__STREAM_DECODER_ABORTED;
+			return f;
+		}
+		if(frame_differs(e, e->vpcm, e->queue + (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
+		off += e->frame_bytes[f];
+	}
+	*bad = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; e->vstate = FLAC__STREAM_DECODER_ABORTED; /* every frame decodes alone but the batch does not */
+	return 0;
+}
+
 /* Code `nsamples` queued wide samples on the engine and replay the per-frame writes. */
 static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final_block)
 {
@@ -358,6 +535,18 @@ static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final
 		e->out, e->out_cap, e->frame_bytes, &total, &last);
 	if(rc != FLACAMD_OK) { e->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR; return 0; }
 	e->last_assignment = last;
+	if(e->verify) { /* write_bitbuffer_ verifies a frame before it is written (:2396-2411): stop ahead of the first bad one */
+		FLAC__StreamEncoderState bad = FLAC__STREAM_ENCODER_OK;
+		const unsigned good = verify_batch(e, nsamples, nframes, (size_t)total, &bad);
+		if(good < nframes) {
+			for(f = 0; f < good; f++) {
+				if(!emit(e, e->out + off, e->frame_bytes[f], N)) return 0;
+				off += e->frame_bytes[f]; e->current_frame_number++; e->streaminfo.data.stream_info.total_samples += N;
+			}
+			e->state = bad;
+			return 0;
+		}
+	}
 	for(f = 0; f < nframes; f++) {
 		const unsigned samples = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
 		if(!emit(e, e->out + off, e->frame_bytes[f], samples)) return 0;
@@ -444,7 +633,17 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e) /* :1310-1377 */
 			if(ok) {
 				put_be(b, si->min_framesize, 3); put_be(b + 3, si->max_framesize, 3);
 				if((ss = e->seek_cb(e, e->streaminfo_offset + 8, e->client_data)) == FLAC__STREAM_ENCODER_SEEK_STATUS_OK) {
-					if(e->write_cb(e, b, 6, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
+					if(e->write_cb(e, b, 6, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+				} else { if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; ok = 0; }
+			}
+			if(ok && e->state == FLAC__STREAM_ENCODER_OK && e->seek_table && e->seek_table->num_points > 0 && e->seektable_offset > 0) { /* :2627-2672 */
+				unsigned i; uint8_t pt[18];
+				FLAC__format_seektable_sort(e->seek_table);
+				if((ss = e->seek_cb(e, e->seektable_offset + FLAC__STREAM_METADATA_HEADER_LENGTH, e->client_data)) == FLAC__STREAM_ENCODER_SEEK_STATUS_OK) {
+					for(i = 0; i < e->seek_table->num_points; i++) {
+						put_be(pt, e->seek_table->points[i].sample_number, 8); put_be(pt + 8, e->seek_table->points[i].stream_offset, 8); put_be(pt + 16, e->seek_table->points[i].frame_samples, 2);
+						if(e->write_cb(e, pt, 18, 0, 0, e->client_data) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) { e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR; break; }
+					}
 				} else if(ss == FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR) e->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
 			}
 			if(e->state != FLAC__STREAM_ENCODER_OK) error = 1;

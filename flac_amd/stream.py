@@ -24,12 +24,151 @@ class StreamInfo(C.Structure):
                 ("md5sum", C.c_uint8 * 16)]
 
 
+class SeekPoint(C.Structure):
+    _fields_ = [("sample_number", C.c_uint64), ("stream_offset", C.c_uint64), ("frame_samples", C.c_uint)]
+
+
+class SeekTable(C.Structure):
+    _fields_ = [("num_points", C.c_uint), ("points", C.POINTER(SeekPoint))]
+
+
+class Application(C.Structure):
+    _fields_ = [("id", C.c_uint8 * 4), ("data", C.POINTER(C.c_uint8))]
+
+
+class VorbisCommentEntry(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("entry", C.POINTER(C.c_uint8))]
+
+
+class VorbisComment(C.Structure):
+    _fields_ = [("vendor_string", VorbisCommentEntry), ("num_comments", C.c_uint32), ("comments", C.POINTER(VorbisCommentEntry))]
+
+
+class CueSheetIndex(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("number", C.c_uint8)]
+
+
+class CueSheetTrack(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("number", C.c_uint8), ("isrc", C.c_char * 13), ("flags", C.c_uint8),   # bit 0: type (1 = non-audio), bit 1: pre_emphasis
+                ("num_indices", C.c_uint8), ("indices", C.POINTER(CueSheetIndex))]
+
+
+class CueSheet(C.Structure):
+    _fields_ = [("media_catalog_number", C.c_char * 129), ("lead_in", C.c_uint64), ("is_cd", C.c_int), ("num_tracks", C.c_uint),
+                ("tracks", C.POINTER(CueSheetTrack))]
+
+
+class Picture(C.Structure):
+    _fields_ = [("type", C.c_int), ("mime_type", C.c_char_p), ("description", C.c_char_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("depth", C.c_uint32), ("colors", C.c_uint32), ("data_length", C.c_uint32), ("data", C.POINTER(C.c_uint8))]
+
+
+class Unknown(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8))]
+
+
 class _MetaData(C.Union):
-    _fields_ = [("stream_info", StreamInfo), ("reserve_", C.c_uint64 * 32)]
+    _fields_ = [("stream_info", StreamInfo), ("padding", C.c_int), ("application", Application), ("seek_table", SeekTable),
+                ("vorbis_comment", VorbisComment), ("cue_sheet", CueSheet), ("picture", Picture), ("unknown", Unknown)]
 
 
 class StreamMetadata(C.Structure):
+    """FLAC__StreamMetadata (include/flac_amd_stream.h).  Blocks built by the helpers below keep their
+    buffers alive in `_keep`; like in C they must outlive the encoder's finish()."""
     _fields_ = [("type", C.c_int), ("is_last", C.c_int), ("length", C.c_uint), ("data", _MetaData)]
+
+
+(META_STREAMINFO, META_PADDING, META_APPLICATION, META_SEEKTABLE, META_VORBIS_COMMENT, META_CUESHEET, META_PICTURE) = range(7)
+SEEKPOINT_PLACEHOLDER = 0xFFFFFFFFFFFFFFFF
+
+
+def _bytes_ptr(b):
+    buf = (C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) + (b"" if len(b) else b"\0"))
+    return buf, C.cast(buf, C.POINTER(C.c_uint8))
+
+
+def padding_block(length):
+    m = StreamMetadata(type=META_PADDING, length=length)
+    m._keep = []
+    return m
+
+
+def application_block(app_id, data):
+    m = StreamMetadata(type=META_APPLICATION, length=4 + len(data))
+    buf, ptr = _bytes_ptr(data)
+    m.data.application.id[:] = list(app_id)
+    m.data.application.data = ptr
+    m._keep = [buf]
+    return m
+
+
+def seektable_block(sample_numbers):
+    """template: target sample numbers (SEEKPOINT_PLACEHOLDER for placeholders); the encoder fills it in"""
+    pts = (SeekPoint * max(1, len(sample_numbers)))()
+    for i, n in enumerate(sample_numbers):
+        pts[i].sample_number = n
+    m = StreamMetadata(type=META_SEEKTABLE, length=18 * len(sample_numbers))
+    m.data.seek_table.num_points = len(sample_numbers)
+    m.data.seek_table.points = C.cast(pts, C.POINTER(SeekPoint))
+    m._keep = [pts]
+    return m
+
+
+def spaced_seekpoints(step_samples, total_samples):
+    """target samples of `-S <n>s`: one point every step_samples from 0, none at total_samples
+    (metadata_object.c:1108-1139)"""
+    num = 1 + total_samples // step_samples - (1 if total_samples % step_samples == 0 else 0)
+    return [i * step_samples for i in range(num)]
+
+
+def vorbis_comment_block(comments):
+    ents = (VorbisCommentEntry * max(1, len(comments)))()
+    keep = [ents]
+    length = 4 + 4
+    for i, c in enumerate(comments):
+        c = c.encode() if isinstance(c, str) else bytes(c)
+        buf, ptr = _bytes_ptr(c)
+        keep.append(buf)
+        ents[i].length, ents[i].entry = len(c), ptr
+        length += 4 + len(c)
+    m = StreamMetadata(type=META_VORBIS_COMMENT, length=length)
+    m.data.vorbis_comment.num_comments = len(comments)
+    m.data.vorbis_comment.comments = C.cast(ents, C.POINTER(VorbisCommentEntry))
+    m._keep = keep
+    return m
+
+
+def picture_block(pic_type, mime, description, width, height, depth, colors, data):
+    mime_b = mime.encode() if isinstance(mime, str) else mime
+    desc_b = description.encode() if isinstance(description, str) else description
+    buf, ptr = _bytes_ptr(data)
+    m = StreamMetadata(type=META_PICTURE, length=4 + 4 + len(mime_b) + 4 + len(desc_b) + 16 + 4 + len(data))
+    p = m.data.picture
+    p.type, p.mime_type, p.description = pic_type, mime_b, desc_b
+    p.width, p.height, p.depth, p.colors, p.data_length, p.data = width, height, depth, colors, len(data), ptr
+    m._keep = [buf, mime_b, desc_b]
+    return m
+
+
+def cuesheet_block(tracks, media_catalog_number=b"", lead_in=88200, is_cd=True):
+    """tracks: list of (offset, number, isrc, is_data, pre_emphasis, [(index_offset, index_number), ...]); the last one is the lead-out"""
+    trs = (CueSheetTrack * len(tracks))()
+    keep = [trs]
+    length = (128 * 8 + 64 + 1 + 7 + 258 * 8 + 8) // 8
+    for i, (off, num, isrc, is_data, pre, idx) in enumerate(tracks):
+        ix = (CueSheetIndex * max(1, len(idx)))()
+        for j, (io, inum) in enumerate(idx):
+            ix[j].offset, ix[j].number = io, inum
+        keep.append(ix)
+        trs[i].offset, trs[i].number, trs[i].isrc, trs[i].flags = off, num, isrc, int(bool(is_data)) | (int(bool(pre)) << 1)
+        trs[i].num_indices, trs[i].indices = len(idx), C.cast(ix, C.POINTER(CueSheetIndex))
+        length += (64 + 8 + 12 * 8 + 1 + 1 + 6 + 13 * 8 + 8) // 8 + len(idx) * (64 + 8 + 3 * 8) // 8
+    m = StreamMetadata(type=META_CUESHEET, length=length)
+    cs = m.data.cue_sheet
+    cs.media_catalog_number, cs.lead_in, cs.is_cd, cs.num_tracks = media_catalog_number, lead_in, int(is_cd), len(tracks)
+    cs.tracks = C.cast(trs, C.POINTER(CueSheetTrack))
+    m._keep = keep
+    return m
 
 
 WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint, C.c_uint, C.c_void_p)
@@ -79,6 +218,12 @@ def _lib():
         L.FLAC__stream_encoder_finish.argtypes = [vp]
         L.flacamd_stream_encoder_set_device.argtypes = [vp, C.c_int]
         L.flacamd_stream_encoder_set_batch_frames.argtypes = [vp, C.c_uint]
+        L.FLAC__stream_encoder_get_verify_decoder_state.argtypes = [vp]
+        L.FLAC__stream_encoder_get_verify_decoder_state.restype = C.c_int
+        L.FLAC__stream_encoder_get_verify_decoder_error_stats.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint)] * 3 + [C.POINTER(C.c_int32)] * 2
+        L.FLAC__stream_encoder_get_verify_decoder_error_stats.restype = None
+        L.flacamd_stream_encoder_inject_verify_fault.argtypes = [vp, C.c_uint64, C.c_uint, C.c_int32]
+        L.flacamd_stream_encoder_inject_frame_fault.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint]
         _bound = True
     return L
 
@@ -120,6 +265,26 @@ class StreamEncoder:
 
     def get_resolved_state_string(self):
         return self._lib.FLAC__stream_encoder_get_resolved_state_string(self._h).decode()
+
+    def set_metadata(self, blocks):
+        """blocks: list of StreamMetadata (see padding_block() etc.); they are kept alive by this object"""
+        self._meta = list(blocks)
+        arr = (C.POINTER(StreamMetadata) * max(1, len(blocks)))(*[C.pointer(b) for b in blocks])
+        self._meta_arr = arr
+        return bool(self._lib.FLAC__stream_encoder_set_metadata(self._h, C.cast(arr, C.c_void_p) if blocks else None, len(blocks)))
+
+    def get_verify_decoder_error_stats(self):
+        a = C.c_uint64()
+        f, c, sm = C.c_uint(), C.c_uint(), C.c_uint()
+        ex, got = C.c_int32(), C.c_int32()
+        self._lib.FLAC__stream_encoder_get_verify_decoder_error_stats(self._h, a, f, c, sm, ex, got)
+        return dict(absolute_sample=a.value, frame_number=f.value, channel=c.value, sample=sm.value, expected=ex.value, got=got.value)
+
+    def inject_verify_fault(self, absolute_sample, channel, mask):
+        return bool(self._lib.flacamd_stream_encoder_inject_verify_fault(self._h, absolute_sample, channel, mask))
+
+    def inject_frame_fault(self, frame_number, byte_index, mask):
+        return bool(self._lib.flacamd_stream_encoder_inject_frame_fault(self._h, frame_number, byte_index, mask))
 
     # callbacks to override -------------------------------------------------------------
     def write_callback(self, data, samples, current_frame):

@@ -10,8 +10,9 @@
  * client sees the same callbacks with the same arguments in the same order, only later
  * (when a batch fills, or at finish()).
  *
- * Not provided in this version (calls fail, nothing is silently ignored): Ogg transport
- * (init_ogg_*), verify mode, user metadata blocks.  set_do_escape_coding and
+ * Verify mode decodes every batch on the device before its frames are written and compares
+ * the result with the queued input.  Not provided (calls fail, nothing is silently ignored):
+ * Ogg transport (init_ogg_*).  set_do_escape_coding and
  * set_rice_parameter_search_dist are accepted and have no effect, exactly as in the
  * reference (stream_encoder.c:1635-1649, :1684-1698).
  */
@@ -69,9 +70,16 @@ typedef enum { FLAC__STREAM_ENCODER_TELL_STATUS_OK, FLAC__STREAM_ENCODER_TELL_ST
 extern const char * const FLAC__StreamEncoderStateString[];
 extern const char * const FLAC__StreamEncoderInitStatusString[];
 
-/* The STREAMINFO block as handed to the metadata callback: same leading layout as the
- * reference's FLAC__StreamMetadata with the stream_info member of its union
- * (include/FLAC/format.h:527-548, :822-850). */
+/* Metadata blocks: types, field names and field order of include/FLAC/format.h:488-850, so
+ * that block objects built by client code (or by the reference's metadata_object helpers) can
+ * be handed to FLAC__stream_encoder_set_metadata unchanged. */
+typedef enum {
+	FLAC__METADATA_TYPE_STREAMINFO = 0, FLAC__METADATA_TYPE_PADDING = 1, FLAC__METADATA_TYPE_APPLICATION = 2,
+	FLAC__METADATA_TYPE_SEEKTABLE = 3, FLAC__METADATA_TYPE_VORBIS_COMMENT = 4, FLAC__METADATA_TYPE_CUESHEET = 5,
+	FLAC__METADATA_TYPE_PICTURE = 6, FLAC__METADATA_TYPE_UNDEFINED = 7
+} FLAC__MetadataType;
+extern const char * const FLAC__MetadataTypeString[];
+
 typedef struct {
 	unsigned min_blocksize, max_blocksize;
 	unsigned min_framesize, max_framesize;
@@ -79,13 +87,82 @@ typedef struct {
 	FLAC__uint64 total_samples;
 	FLAC__byte md5sum[16];
 } FLAC__StreamMetadata_StreamInfo;
+#define FLAC__STREAM_METADATA_STREAMINFO_LENGTH (34u)
+#define FLAC__STREAM_METADATA_HEADER_LENGTH (4u)
+
+typedef struct { int dummy; } FLAC__StreamMetadata_Padding;                    /* `length` zero bytes */
+typedef struct { FLAC__byte id[4]; FLAC__byte *data; } FLAC__StreamMetadata_Application; /* data: length-4 bytes */
+
+typedef struct { FLAC__uint64 sample_number, stream_offset; unsigned frame_samples; } FLAC__StreamMetadata_SeekPoint;
+#define FLAC__STREAM_METADATA_SEEKPOINT_LENGTH (18u)
+#define FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER_VALUE 0xffffffffffffffffull
+extern const FLAC__uint64 FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER;
+typedef struct { unsigned num_points; FLAC__StreamMetadata_SeekPoint *points; } FLAC__StreamMetadata_SeekTable;
+
+typedef struct { FLAC__uint32 length; FLAC__byte *entry; } FLAC__StreamMetadata_VorbisComment_Entry;
+typedef struct {
+	FLAC__StreamMetadata_VorbisComment_Entry vendor_string;   /* ignored on write: the library's own is written */
+	FLAC__uint32 num_comments;
+	FLAC__StreamMetadata_VorbisComment_Entry *comments;
+} FLAC__StreamMetadata_VorbisComment;
+
+typedef struct { FLAC__uint64 offset; FLAC__byte number; } FLAC__StreamMetadata_CueSheet_Index;
+typedef struct {
+	FLAC__uint64 offset;
+	FLAC__byte number;
+	char isrc[13];
+	unsigned type:1;
+	unsigned pre_emphasis:1;
+	FLAC__byte num_indices;
+	FLAC__StreamMetadata_CueSheet_Index *indices;
+} FLAC__StreamMetadata_CueSheet_Track;
+typedef struct {
+	char media_catalog_number[129];
+	FLAC__uint64 lead_in;
+	FLAC__bool is_cd;
+	unsigned num_tracks;
+	FLAC__StreamMetadata_CueSheet_Track *tracks;
+} FLAC__StreamMetadata_CueSheet;
+
+typedef enum {
+	FLAC__STREAM_METADATA_PICTURE_TYPE_OTHER = 0, FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON_STANDARD = 1,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON = 2, FLAC__STREAM_METADATA_PICTURE_TYPE_FRONT_COVER = 3,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_BACK_COVER = 4, FLAC__STREAM_METADATA_PICTURE_TYPE_UNDEFINED = 21
+} FLAC__StreamMetadata_Picture_Type;   /* 5..20: the remaining ID3v2 APIC kinds, passed through as numbers */
+typedef struct {
+	FLAC__StreamMetadata_Picture_Type type;
+	char *mime_type;            /* NUL-terminated printable ASCII */
+	FLAC__byte *description;    /* NUL-terminated UTF-8 */
+	FLAC__uint32 width, height, depth, colors;
+	FLAC__uint32 data_length;
+	FLAC__byte *data;
+} FLAC__StreamMetadata_Picture;
+
+typedef struct { FLAC__byte *data; } FLAC__StreamMetadata_Unknown;
 
 typedef struct {
-	int type;            /* 0 = STREAMINFO */
-	FLAC__bool is_last;
-	unsigned length;
-	union { FLAC__StreamMetadata_StreamInfo stream_info; uint64_t reserve_[32]; } data;
+	FLAC__MetadataType type;
+	FLAC__bool is_last;      /* set by the encoder when the block is written */
+	unsigned length;         /* bytes of block data, without the 4-byte block header */
+	union {
+		FLAC__StreamMetadata_StreamInfo stream_info;
+		FLAC__StreamMetadata_Padding padding;
+		FLAC__StreamMetadata_Application application;
+		FLAC__StreamMetadata_SeekTable seek_table;
+		FLAC__StreamMetadata_VorbisComment vorbis_comment;
+		FLAC__StreamMetadata_CueSheet cue_sheet;
+		FLAC__StreamMetadata_Picture picture;
+		FLAC__StreamMetadata_Unknown unknown;
+	} data;
 } FLAC__StreamMetadata;
+
+/* format.c:248-314, :396-523: the legality checks init applies to client blocks, and the sort the
+ * encoder applies to a seek table before it is written back at finish(). */
+FLAC__bool FLAC__format_seektable_is_legal(const FLAC__StreamMetadata_SeekTable *seek_table);
+unsigned FLAC__format_seektable_sort(FLAC__StreamMetadata_SeekTable *seek_table);
+FLAC__bool FLAC__format_vorbiscomment_entry_is_legal(const FLAC__byte *entry, unsigned length);
+FLAC__bool FLAC__format_cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet *cue_sheet, FLAC__bool check_cd_da_subset, const char **violation);
+FLAC__bool FLAC__format_picture_is_legal(const FLAC__StreamMetadata_Picture *picture, const char **violation);
 
 typedef struct FLAC__StreamEncoder FLAC__StreamEncoder;
 
@@ -100,7 +177,7 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void);
 void FLAC__stream_encoder_delete(FLAC__StreamEncoder *encoder);
 
 /* setters: legal only before init, return false afterwards (stream_encoder.c:1430-1745) */
-FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value); /* true is refused */
+FLAC__bool FLAC__stream_encoder_set_verify(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_set_streamable_subset(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_set_channels(FLAC__StreamEncoder *encoder, unsigned value);
 FLAC__bool FLAC__stream_encoder_set_bits_per_sample(FLAC__StreamEncoder *encoder, unsigned value);
@@ -119,7 +196,9 @@ FLAC__bool FLAC__stream_encoder_set_min_residual_partition_order(FLAC__StreamEnc
 FLAC__bool FLAC__stream_encoder_set_max_residual_partition_order(FLAC__StreamEncoder *encoder, unsigned value);
 FLAC__bool FLAC__stream_encoder_set_rice_parameter_search_dist(FLAC__StreamEncoder *encoder, unsigned value);
 FLAC__bool FLAC__stream_encoder_set_total_samples_estimate(FLAC__StreamEncoder *encoder, FLAC__uint64 value);
-FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *encoder, FLAC__StreamMetadata **metadata, unsigned num_blocks); /* only (NULL, 0) */
+/* :1711-1741: the pointer array is copied, the blocks are not: they must stay valid until finish(), and a
+ * SEEKTABLE block is filled in (and sorted) in place */
+FLAC__bool FLAC__stream_encoder_set_metadata(FLAC__StreamEncoder *encoder, FLAC__StreamMetadata **metadata, unsigned num_blocks);
 /* semi-private hooks used by the reference's tools (stream_encoder.c:1419, :1747-1778) */
 FLAC__bool FLAC__stream_encoder_disable_constant_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_disable_fixed_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
@@ -284,6 +363,19 @@ FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *decoder, FLAC
 /* additions of this implementation: HIP device (default 0), frames per device batch (default 2048) */
 FLAC__bool flacamd_stream_decoder_set_device(FLAC__StreamDecoder *decoder, int device);
 FLAC__bool flacamd_stream_decoder_set_batch_frames(FLAC__StreamDecoder *decoder, unsigned frames);
+
+/* ---- encoder verify mode (declared here because they use the decoder's state type) ----
+ * stream_encoder.c:1788-1827.  The verify decoder is the device decoder, run on every batch before
+ * its frames reach the write callback; frames ahead of a failing frame are still written, like
+ * in the reference, and the failing frame is not. */
+FLAC__StreamDecoderState FLAC__stream_encoder_get_verify_decoder_state(const FLAC__StreamEncoder *encoder);
+void FLAC__stream_encoder_get_verify_decoder_error_stats(const FLAC__StreamEncoder *encoder, FLAC__uint64 *absolute_sample, unsigned *frame_number, unsigned *channel, unsigned *sample, FLAC__int32 *expected, FLAC__int32 *got);
+/* Test hook of this implementation (no counterpart in the reference, like its disable_* hooks a
+ * way to reach a path that correct code never takes): XOR `mask` into the retained copy of one
+ * input sample just before the comparison, as a bit flip in host memory would. */
+FLAC__bool flacamd_stream_encoder_inject_verify_fault(FLAC__StreamEncoder *encoder, FLAC__uint64 absolute_sample, unsigned channel, FLAC__int32 mask);
+/* Second test hook: XOR `mask` into byte `byte_index` of frame `frame_number` before it is verified. */
+FLAC__bool flacamd_stream_encoder_inject_frame_fault(FLAC__StreamEncoder *encoder, unsigned frame_number, unsigned byte_index, unsigned mask);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#\s*define.*$", "", text, flags=re.M)   # object-like macros are not symbols
     return sorted(set(re.findall(r"\b(flacamd_[a-z0-9_]+|FLAC__[A-Za-z0-9_]+)\s*\((?!\*)", text)))
 
 
@@ -106,7 +107,10 @@ def test_stream_encoder_defaults_setters_and_getters():
     # accepted and inert, as in the reference (stream_encoder.c:1635-1649, :1684-1698)
     assert e.set_do_escape_coding(1) and e.get_do_escape_coding() == 0
     assert e.set_rice_parameter_search_dist(3) and e.get_rice_parameter_search_dist() == 0
-    assert not e.set_verify(1) and e.set_verify(0)
+    assert e.set_verify(1) and e.get_verify() == 1 and e.set_verify(0) and e.get_verify() == 0
+    assert e.get_verify_decoder_state() == stream.DEC_UNINITIALIZED   # verify off (:1788-1797)
+    assert e.get_verify_decoder_error_stats() == dict(absolute_sample=0, frame_number=0, channel=0, sample=0, expected=0, got=0)
+    assert e.set_metadata([stream.padding_block(16)]) and e.set_metadata([])
     assert e.set_apodization("hann;tukey(0.25);nonsense;gauss(0.2)")
     assert e.finish()  # finish on an uninitialised encoder is a successful no-op (:1314-1315)
     e.close()
