@@ -204,3 +204,135 @@ int flacamd_metadata_block_image(const FLAC__StreamMetadata *m, const char *vend
 	*out = s.p; *out_len = s.n;
 	return 0;
 }
+
+/* ---- parsing (what read_metadata_ builds for the client, /root/reference/src/libFLAC/stream_decoder.c:1427-1602,
+ * :1675-1975): every pointer inside the object is malloc'ed here and released by
+ * flacamd_metadata_block_free.  Truncated or inconsistent block data fails instead of reading past `n`. ---- */
+
+typedef struct { const uint8_t *p; size_t n, pos; int bad; } source;
+static uint64_t get_be(source *s, unsigned nbytes)
+{
+	uint64_t v = 0; unsigned i;
+	if(s->bad || s->n - s->pos < nbytes) { s->bad = 1; return 0; }
+	for(i = 0; i < nbytes; i++) v = (v << 8) | s->p[s->pos++];
+	return v;
+}
+static uint32_t get_le32(source *s)
+{
+	uint32_t v;
+	if(s->bad || s->n - s->pos < 4) { s->bad = 1; return 0; }
+	v = (uint32_t)s->p[s->pos] | ((uint32_t)s->p[s->pos + 1] << 8) | ((uint32_t)s->p[s->pos + 2] << 16) | ((uint32_t)s->p[s->pos + 3] << 24);
+	s->pos += 4;
+	return v;
+}
+static void get_bytes(source *s, void *dst, size_t n)
+{
+	if(s->bad || s->n - s->pos < n) { s->bad = 1; return; }
+	memcpy(dst, s->p + s->pos, n); s->pos += n;
+}
+/* n bytes as a fresh NUL-terminated buffer; NULL (and no error) when n == 0 and !always */
+static uint8_t *get_string(source *s, size_t n, int always)
+{
+	uint8_t *b;
+	if(s->bad || s->n - s->pos < n) { s->bad = 1; return 0; }
+	if(n == 0 && !always) return 0;
+	b = (uint8_t*)malloc(n + 1);
+	if(!b) { s->bad = 1; return 0; }
+	memcpy(b, s->p + s->pos, n); b[n] = 0; s->pos += n;
+	return b;
+}
+
+void flacamd_metadata_block_free(FLAC__StreamMetadata *m)
+{
+	unsigned i;
+	switch(m->type) {
+	case FLAC__METADATA_TYPE_STREAMINFO: case FLAC__METADATA_TYPE_PADDING: break;
+	case FLAC__METADATA_TYPE_APPLICATION: free(m->data.application.data); break;
+	case FLAC__METADATA_TYPE_SEEKTABLE: free(m->data.seek_table.points); break;
+	case FLAC__METADATA_TYPE_VORBIS_COMMENT:
+		free(m->data.vorbis_comment.vendor_string.entry);
+		if(m->data.vorbis_comment.comments) for(i = 0; i < m->data.vorbis_comment.num_comments; i++) free(m->data.vorbis_comment.comments[i].entry);
+		free(m->data.vorbis_comment.comments);
+		break;
+	case FLAC__METADATA_TYPE_CUESHEET:
+		if(m->data.cue_sheet.tracks) for(i = 0; i < m->data.cue_sheet.num_tracks; i++) free(m->data.cue_sheet.tracks[i].indices);
+		free(m->data.cue_sheet.tracks);
+		break;
+	case FLAC__METADATA_TYPE_PICTURE: free(m->data.picture.mime_type); free(m->data.picture.description); free(m->data.picture.data); break;
+	default: free(m->data.unknown.data); break;
+	}
+	memset(&m->data, 0, sizeof m->data);
+}
+
+int flacamd_metadata_block_parse(unsigned type, int is_last, const uint8_t *data, size_t n, FLAC__StreamMetadata *m)
+{
+	source s = { data, n, 0, 0 };
+	unsigned i, j;
+	memset(m, 0, sizeof *m);
+	m->type = (FLAC__MetadataType)type; m->is_last = is_last ? 1 : 0; m->length = (unsigned)n;
+	switch(type) {
+	case FLAC__METADATA_TYPE_PADDING: break;
+	case FLAC__METADATA_TYPE_APPLICATION:
+		get_bytes(&s, m->data.application.id, 4);
+		if(!s.bad && n > 4) { m->data.application.data = (FLAC__byte*)malloc(n - 4); if(!m->data.application.data) s.bad = 1; else get_bytes(&s, m->data.application.data, n - 4); }
+		break;
+	case FLAC__METADATA_TYPE_SEEKTABLE: { /* a trailing partial point is ignored (:1706-1712) */
+		FLAC__StreamMetadata_SeekTable *t = &m->data.seek_table;
+		t->num_points = (unsigned)(n / FLAC__STREAM_METADATA_SEEKPOINT_LENGTH);
+		t->points = (FLAC__StreamMetadata_SeekPoint*)calloc(t->num_points ? t->num_points : 1, sizeof t->points[0]);
+		if(!t->points) { s.bad = 1; break; }
+		for(i = 0; i < t->num_points; i++) { t->points[i].sample_number = get_be(&s, 8); t->points[i].stream_offset = get_be(&s, 8); t->points[i].frame_samples = (unsigned)get_be(&s, 2); }
+		break; }
+	case FLAC__METADATA_TYPE_VORBIS_COMMENT: {
+		FLAC__StreamMetadata_VorbisComment *vc = &m->data.vorbis_comment;
+		vc->vendor_string.length = get_le32(&s);
+		vc->vendor_string.entry = get_string(&s, vc->vendor_string.length, 0);
+		vc->num_comments = get_le32(&s);
+		if(s.bad) break;
+		if((size_t)vc->num_comments > (n - s.pos) / 4) { s.bad = 1; vc->num_comments = 0; break; } /* every comment needs its length word */
+		if(vc->num_comments) {
+			vc->comments = (FLAC__StreamMetadata_VorbisComment_Entry*)calloc(vc->num_comments, sizeof vc->comments[0]);
+			if(!vc->comments) { s.bad = 1; vc->num_comments = 0; break; }
+			for(i = 0; i < vc->num_comments && !s.bad; i++) { vc->comments[i].length = get_le32(&s); vc->comments[i].entry = get_string(&s, vc->comments[i].length, 0); }
+		}
+		break; }
+	case FLAC__METADATA_TYPE_CUESHEET: {
+		FLAC__StreamMetadata_CueSheet *cs = &m->data.cue_sheet;
+		get_bytes(&s, cs->media_catalog_number, 128);
+		cs->lead_in = get_be(&s, 8);
+		cs->is_cd = (get_be(&s, 1) & 0x80) ? 1 : 0;
+		s.pos += 258; if(s.pos > n) s.bad = 1;
+		cs->num_tracks = (unsigned)get_be(&s, 1);
+		if(s.bad || cs->num_tracks == 0) break;
+		cs->tracks = (FLAC__StreamMetadata_CueSheet_Track*)calloc(cs->num_tracks, sizeof cs->tracks[0]);
+		if(!cs->tracks) { s.bad = 1; cs->num_tracks = 0; break; }
+		for(i = 0; i < cs->num_tracks && !s.bad; i++) {
+			FLAC__StreamMetadata_CueSheet_Track *t = &cs->tracks[i];
+			unsigned flags;
+			t->offset = get_be(&s, 8); t->number = (FLAC__byte)get_be(&s, 1); get_bytes(&s, t->isrc, 12);
+			flags = (unsigned)get_be(&s, 1); t->type = (flags >> 7) & 1u; t->pre_emphasis = (flags >> 6) & 1u;
+			s.pos += 13; if(s.pos > n) s.bad = 1;
+			t->num_indices = (FLAC__byte)get_be(&s, 1);
+			if(s.bad || t->num_indices == 0) continue;
+			t->indices = (FLAC__StreamMetadata_CueSheet_Index*)calloc(t->num_indices, sizeof t->indices[0]);
+			if(!t->indices) { s.bad = 1; t->num_indices = 0; break; }
+			for(j = 0; j < t->num_indices; j++) { t->indices[j].offset = get_be(&s, 8); t->indices[j].number = (FLAC__byte)get_be(&s, 1); s.pos += 3; if(s.pos > n) s.bad = 1; }
+		}
+		break; }
+	case FLAC__METADATA_TYPE_PICTURE: {
+		FLAC__StreamMetadata_Picture *pic = &m->data.picture;
+		uint32_t len;
+		pic->type = (FLAC__StreamMetadata_Picture_Type)get_be(&s, 4);
+		len = (uint32_t)get_be(&s, 4); pic->mime_type = (char*)get_string(&s, len, 1);
+		len = (uint32_t)get_be(&s, 4); pic->description = get_string(&s, len, 1);
+		pic->width = (uint32_t)get_be(&s, 4); pic->height = (uint32_t)get_be(&s, 4); pic->depth = (uint32_t)get_be(&s, 4); pic->colors = (uint32_t)get_be(&s, 4);
+		pic->data_length = (uint32_t)get_be(&s, 4);
+		pic->data = get_string(&s, pic->data_length, 1);
+		break; }
+	default:
+		if(n) { m->data.unknown.data = (FLAC__byte*)malloc(n); if(!m->data.unknown.data) s.bad = 1; else get_bytes(&s, m->data.unknown.data, n); }
+		break;
+	}
+	if(s.bad) { flacamd_metadata_block_free(m); return -1; }
+	return 0;
+}

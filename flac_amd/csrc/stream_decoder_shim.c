@@ -11,6 +11,7 @@
 #include "../../include/flac_amd_stream.h"
 #include "../../include/flac_amd_engine.h"
 #include "host_md5.h"
+#include "metadata_blocks.h"
 #include <stdlib.h>
 #include <sys/types.h>
 #include <sys/stat.h>
@@ -28,7 +29,9 @@ const char * const FLAC__StreamDecoderErrorStatusString[] = { /* :162-167 */
 
 struct FLAC__StreamDecoder {
 	FLAC__StreamDecoderState state;
-	FLAC__bool md5_checking, do_md5, respond_streaminfo;
+	FLAC__bool md5_checking, do_md5;
+	FLAC__bool respond[128];                 /* metadata_filter (:148-151): block types handed to the metadata callback */
+	FLAC__byte *app_ids; size_t app_ids_count;  /* exceptions to respond[APPLICATION], 4 bytes each (:780-865) */
 	int device; unsigned batch_frames;
 	FLAC__StreamDecoderReadCallback read_cb; FLAC__StreamDecoderSeekCallback seek_cb; FLAC__StreamDecoderTellCallback tell_cb;
 	FLAC__StreamDecoderLengthCallback length_cb; FLAC__StreamDecoderEofCallback eof_cb; FLAC__StreamDecoderWriteCallback write_cb;
@@ -52,10 +55,11 @@ struct FLAC__StreamDecoder {
 static void dec_defaults(FLAC__StreamDecoder *d) /* set_defaults_, :1247-1268 */
 {
 	const int device = d->device; const unsigned batch = d->batch_frames;
+	free(d->app_ids);
 	memset(d, 0, sizeof *d);
 	d->device = device; d->batch_frames = batch ? batch : 2048u;
 	d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
-	d->respond_streaminfo = 1; d->md5_checking = 0;
+	d->respond[FLAC__METADATA_TYPE_STREAMINFO] = 1; d->md5_checking = 0;
 }
 
 FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
@@ -76,6 +80,7 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 {
 	if(!d) return;
 	(void)FLAC__stream_decoder_finish(d);
+	free(d->app_ids);
 	free(d);
 }
 
@@ -83,10 +88,49 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 DEC_SETTER(FLAC__stream_decoder_set_md5_checking, FLAC__bool, d->md5_checking = value)
 DEC_SETTER(flacamd_stream_decoder_set_device, int, if(value < 0) return 0; d->device = value)
 DEC_SETTER(flacamd_stream_decoder_set_batch_frames, unsigned, if(value == 0) return 0; d->batch_frames = value)
-FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *d, int type) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED || type != 0) return 0; d->respond_streaminfo = 1; return 1; }
-FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *d) { (void)d; return 0; }
-FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *d, int type) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; if(type == 0) d->respond_streaminfo = 0; return 1; }
-FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *d) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; d->respond_streaminfo = 0; return 1; }
+/* the metadata filter (:762-877) */
+#define UNINIT(d) ((d) && (d)->state == FLAC__STREAM_DECODER_UNINITIALIZED)
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *d, int type)
+{
+	if(!UNINIT(d) || (unsigned)type > 126u) return 0;
+	d->respond[type] = 1;
+	if(type == FLAC__METADATA_TYPE_APPLICATION) d->app_ids_count = 0;
+	return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *d, int type)
+{
+	if(!UNINIT(d) || (unsigned)type > 126u) return 0;
+	d->respond[type] = 0;
+	if(type == FLAC__METADATA_TYPE_APPLICATION) d->app_ids_count = 0;
+	return 1;
+}
+static FLAC__bool add_app_id(FLAC__StreamDecoder *d, const FLAC__byte id[4])
+{
+	FLAC__byte *n = (FLAC__byte*)realloc(d->app_ids, 4 * (d->app_ids_count + 1));
+	if(!n) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+	d->app_ids = n; memcpy(n + 4 * d->app_ids_count, id, 4); d->app_ids_count++;
+	return 1;
+}
+/* an id listed while APPLICATION blocks are ignored is an exception that is delivered, and the other way round */
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *d, const FLAC__byte id[4])
+{
+	if(!UNINIT(d) || !id) return 0;
+	return d->respond[FLAC__METADATA_TYPE_APPLICATION] ? 1 : add_app_id(d, id);
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *d, const FLAC__byte id[4])
+{
+	if(!UNINIT(d) || !id) return 0;
+	return !d->respond[FLAC__METADATA_TYPE_APPLICATION] ? 1 : add_app_id(d, id);
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *d)
+{
+	unsigned i;
+	if(!UNINIT(d)) return 0;
+	for(i = 0; i < 128; i++) d->respond[i] = 1;
+	d->app_ids_count = 0;
+	return 1;
+}
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *d) { if(!UNINIT(d)) return 0; memset(d->respond, 0, sizeof d->respond); d->app_ids_count = 0; return 1; }
 
 FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *d) { return d->state; }
 const char *FLAC__stream_decoder_get_resolved_state_string(const FLAC__StreamDecoder *d) { return FLAC__StreamDecoderStateString[d->state]; }
@@ -308,9 +352,27 @@ static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
 		d->has_streaminfo = 1;
 		{ static const uint8_t zero[16] = {0}; if(0 == memcmp(si->md5sum, zero, 16)) d->do_md5 = 0; } /* :1620-1621 */
 		d->last.channels = si->channels; d->last.bits_per_sample = si->bits_per_sample; d->last.sample_rate = si->sample_rate;
-		if(d->respond_streaminfo && d->metadata_cb && !d->is_seeking) d->metadata_cb(d, &d->streaminfo, d->client_data);
+		if(d->respond[FLAC__METADATA_TYPE_STREAMINFO] && d->metadata_cb && !d->is_seeking) d->metadata_cb(d, &d->streaminfo, d->client_data);
 	}
-	else if(!skip_bytes(d, length)) return 0;
+	else {
+		/* :1450-1592: deliver the block if its type passes the filter; for APPLICATION blocks the listed ids invert it */
+		FLAC__bool deliver = type < 127 && d->respond[type] && d->metadata_cb && !d->is_seeking;
+		if(type == FLAC__METADATA_TYPE_APPLICATION && d->app_ids_count && d->metadata_cb && !d->is_seeking && length >= 4) {
+			size_t i;
+			if(!fill(d, 4)) return 0;
+			if(avail(d) >= 4) for(i = 0; i < d->app_ids_count; i++) if(0 == memcmp(d->in + d->in_pos, d->app_ids + 4 * i, 4)) { deliver = !d->respond[type]; break; }
+		}
+		if(deliver) {
+			FLAC__StreamMetadata block;
+			if(!fill(d, (size_t)length)) return 0;
+			if(avail(d) < length) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+			if(flacamd_metadata_block_parse(type, (int)is_last, d->in + d->in_pos, (size_t)length, &block) != 0) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+			d->in_pos += (size_t)length;
+			d->metadata_cb(d, &block, d->client_data);
+			flacamd_metadata_block_free(&block);
+		}
+		else if(!skip_bytes(d, length)) return 0;
+	}
 	if(is_last) return start_frames(d);
 	return 1;
 }

@@ -390,6 +390,35 @@ class FileEncoder(StreamEncoder):
         return status
 
 
+def _block_to_dict(b):
+    """A delivered metadata block as plain Python data (the C object is only valid during the callback)."""
+    d = dict(type=b.type, is_last=bool(b.is_last), length=b.length)
+    u = b.data
+    if b.type == META_APPLICATION:
+        d.update(id=bytes(u.application.id), data=C.string_at(u.application.data, b.length - 4) if b.length > 4 else b"")
+    elif b.type == META_SEEKTABLE:
+        t = u.seek_table
+        d.update(points=[(t.points[i].sample_number, t.points[i].stream_offset, t.points[i].frame_samples) for i in range(t.num_points)])
+    elif b.type == META_VORBIS_COMMENT:
+        v = u.vorbis_comment
+        d.update(vendor=C.string_at(v.vendor_string.entry, v.vendor_string.length) if v.vendor_string.length else b"",
+                 comments=[C.string_at(v.comments[i].entry, v.comments[i].length) if v.comments[i].length else b"" for i in range(v.num_comments)])
+    elif b.type == META_CUESHEET:
+        cs = u.cue_sheet
+        tracks = []
+        for i in range(cs.num_tracks):
+            t = cs.tracks[i]
+            tracks.append((t.offset, t.number, t.isrc, bool(t.flags & 1), bool(t.flags & 2), [(t.indices[j].offset, t.indices[j].number) for j in range(t.num_indices)]))
+        d.update(media_catalog_number=cs.media_catalog_number, lead_in=cs.lead_in, is_cd=bool(cs.is_cd), tracks=tracks)
+    elif b.type == META_PICTURE:
+        p = u.picture
+        d.update(picture_type=p.type, mime_type=p.mime_type, description=p.description, width=p.width, height=p.height, depth=p.depth,
+                 colors=p.colors, data=C.string_at(p.data, p.data_length))
+    elif b.type != META_PADDING:
+        d.update(data=C.string_at(u.unknown.data, b.length) if b.length else b"")
+    return d
+
+
 # ---- decoder object -----------------------------------------------------------------------
 
 (DEC_SEARCH_FOR_METADATA, DEC_READ_METADATA, DEC_SEARCH_FOR_FRAME_SYNC, DEC_READ_FRAME, DEC_END_OF_STREAM, DEC_OGG_ERROR, DEC_SEEK_ERROR,
@@ -448,6 +477,8 @@ def _dec_lib():
         L.FLAC__stream_decoder_init_file.argtypes = [vp, C.c_char_p, D_WRITE_CB, D_META_CB, D_ERROR_CB, vp]
         L.flacamd_stream_decoder_set_device.argtypes = [vp, C.c_int]
         L.flacamd_stream_decoder_set_batch_frames.argtypes = [vp, C.c_uint]
+        L.FLAC__stream_decoder_set_metadata_respond_application.argtypes = [vp, C.c_char_p]
+        L.FLAC__stream_decoder_set_metadata_ignore_application.argtypes = [vp, C.c_char_p]
         _dec_bound = True
     return L
 
@@ -461,6 +492,7 @@ class StreamDecoder:
         self._h = C.c_void_p(self._lib.FLAC__stream_decoder_new())
         self.data, self.pos, self.seekable, self.read_chunk = data, 0, seekable, read_chunk
         self.frames, self.errors, self.streaminfo = [], [], None
+        self.metadata = []   # every non-STREAMINFO block delivered, as plain dicts (see _block_to_dict)
         self._keep = None
 
     def close(self):
@@ -488,6 +520,12 @@ class StreamDecoder:
     def get_resolved_state_string(self):
         return self._lib.FLAC__stream_decoder_get_resolved_state_string(self._h).decode()
 
+    def set_metadata_respond_application(self, app_id):
+        return bool(self._lib.FLAC__stream_decoder_set_metadata_respond_application(self._h, bytes(app_id)))
+
+    def set_metadata_ignore_application(self, app_id):
+        return bool(self._lib.FLAC__stream_decoder_set_metadata_ignore_application(self._h, bytes(app_id)))
+
     def get_decode_position(self):
         v = C.c_uint64(0)
         return int(v.value) if self._lib.FLAC__stream_decoder_get_decode_position(self._h, C.byref(v)) else None
@@ -509,6 +547,9 @@ class StreamDecoder:
             return int(self.write_callback(hdr, pcm) or 0)
 
         def m(_d, md, _cd):
+            if md.contents.type != META_STREAMINFO:
+                self.metadata.append(_block_to_dict(md.contents))
+                return
             si = md.contents.data.stream_info
             self.streaminfo = dict(min_blocksize=si.min_blocksize, max_blocksize=si.max_blocksize, min_framesize=si.min_framesize,
                                    max_framesize=si.max_framesize, sample_rate=si.sample_rate, channels=si.channels,

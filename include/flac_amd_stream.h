@@ -250,11 +250,10 @@ FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *encoder,
  * replayed frame by frame in stream order: the write callback sees the same FLAC__FrameHeader
  * fields and the same planar FLAC__int32 buffers as with the reference.
  *
- * Differences, none silent: only the STREAMINFO block is delivered to the metadata callback
- * (requests for other block types return false); Ogg transport is not provided; a stream must
- * begin with STREAMINFO; a batch that contains corrupt frames is reported through the error
- * callback and decoding stops (state ABORTED) instead of resynchronising inside the batch;
- * FLAC__Frame carries the header and the footer CRC but no per-subframe records.
+ * Differences, none silent: Ogg transport is not provided; a stream must begin with STREAMINFO; a
+ * batch that contains corrupt frames is reported through the error callback and decoding stops
+ * (state ABORTED) instead of resynchronising inside the batch; FLAC__Frame carries the header and
+ * the footer CRC but no per-subframe records.
  * ====================================================================================== */
 
 typedef enum {
@@ -331,9 +330,13 @@ FLAC__StreamDecoder *FLAC__stream_decoder_new(void);
 void FLAC__stream_decoder_delete(FLAC__StreamDecoder *decoder);
 
 FLAC__bool FLAC__stream_decoder_set_md5_checking(FLAC__StreamDecoder *decoder, FLAC__bool value);
-FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *decoder, int type);   /* only type 0 (STREAMINFO) */
-FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *decoder);          /* false: other block types are not delivered */
+/* the metadata filter (stream_decoder.c:762-877): by default only STREAMINFO reaches the metadata callback; blocks
+ * handed to the callback are only valid during the call */
+FLAC__bool FLAC__stream_decoder_set_metadata_respond(FLAC__StreamDecoder *decoder, int type);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_application(FLAC__StreamDecoder *decoder, const FLAC__byte id[4]);
+FLAC__bool FLAC__stream_decoder_set_metadata_respond_all(FLAC__StreamDecoder *decoder);
 FLAC__bool FLAC__stream_decoder_set_metadata_ignore(FLAC__StreamDecoder *decoder, int type);
+FLAC__bool FLAC__stream_decoder_set_metadata_ignore_application(FLAC__StreamDecoder *decoder, const FLAC__byte id[4]);
 FLAC__bool FLAC__stream_decoder_set_metadata_ignore_all(FLAC__StreamDecoder *decoder);
 
 FLAC__StreamDecoderState FLAC__stream_decoder_get_state(const FLAC__StreamDecoder *decoder);

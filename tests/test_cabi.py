@@ -163,7 +163,8 @@ def test_stream_decoder_init_checks_and_no_cpu_path():
     # a seek callback without tell / length / eof is refused
     assert L.FLAC__stream_decoder_init_stream(d._h, rd, stream.D_SEEK_CB(lambda *a: 0), stream.D_TELL_CB(), stream.D_LENGTH_CB(), stream.D_EOF_CB(), wr, stream.D_META_CB(), er, None) == stream.DEC_INIT_INVALID_CALLBACKS
     assert d.set_md5_checking(1) and d.get_md5_checking() == 1
-    assert not d.set_metadata_respond(4) and d.set_metadata_respond(0) and not d.set_metadata_respond_all()
+    assert d.set_metadata_respond(4) and d.set_metadata_respond(0) and d.set_metadata_respond_all() and not d.set_metadata_respond(127)
+    assert d.set_metadata_ignore_application(b"abcd") and d.set_metadata_ignore(2) and d.set_metadata_respond_application(b"abcd")
     assert not d.process_single() and d.finish()
     if engine.device_count() == 0:
         assert d.init() == stream.DEC_INIT_MEMORY_ALLOCATION_ERROR and d.get_state() == stream.DEC_UNINITIALIZED

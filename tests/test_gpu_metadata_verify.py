@@ -185,3 +185,46 @@ def test_verify_reports_a_frame_that_does_not_decode(gpu_engine):
     assert not e.finish() and e.get_state() == stream.VERIFY_DECODER_ERROR
     assert e.get_resolved_state_string() == "FLAC__STREAM_DECODER_UNINITIALIZED"
     e.close()
+
+
+def test_decoder_delivers_the_blocks_the_filter_selects(gpu_engine, tmp_path):
+    """Round trip of every block type through the decoder's metadata filter (stream_decoder.c:762-877, :1427-1602)."""
+    n = 588 * 100
+    pcm = synth.music_like(1.5, seed=18)[:n]
+    png = _png(4, 4)
+    tracks = [(0, 1, b"ABCDE1234567", False, True, [(0, 1), (588, 2)]), (n, 170, b"", False, False, [])]
+    blocks = [stream.seektable_block([0, 30000, stream.SEEKPOINT_PLACEHOLDER]), stream.application_block(b"aaaa", b"first"),
+              stream.vorbis_comment_block(["TITLE=x", "EMPTY=", "K=ü"]), stream.cuesheet_block(tracks, media_catalog_number=b"42"),
+              stream.application_block(b"bbbb", b""), stream.picture_block(3, "image/png", "cover ü", 4, 4, 24, 0, png), stream.padding_block(33)]
+    data = _encode_file(tmp_path, pcm, blocks, level=5)
+
+    def run(setup):
+        d = stream.StreamDecoder(data)
+        setup(d)
+        assert d.init() == stream.DEC_INIT_OK and d.process_until_end_of_stream() and d.finish()
+        out = d.metadata, d.streaminfo, d.pcm()
+        d.close()
+        return out
+
+    meta, si, got = run(lambda d: d.set_metadata_respond_all())
+    assert np.array_equal(got, pcm) and si["total_samples"] == n
+    assert [m["type"] for m in meta] == [3, 2, 4, 5, 2, 6, 1] and [m["is_last"] for m in meta] == [False] * 6 + [True]
+    assert meta[0]["points"] == [(0, 0, 4096), (28672, meta[0]["points"][1][1], 4096), (stream.SEEKPOINT_PLACEHOLDER, 0, 0)]
+    assert (meta[1]["id"], meta[1]["data"], meta[4]["id"], meta[4]["data"]) == (b"aaaa", b"first", b"bbbb", b"")
+    assert meta[2]["vendor"] == b"reference libFLAC 1.2.1 20070917" and meta[2]["comments"] == [b"TITLE=x", b"EMPTY=", "K=ü".encode()]
+    cs = meta[3]
+    assert (cs["media_catalog_number"], cs["lead_in"], cs["is_cd"]) == (b"42", 88200, True) and cs["tracks"] == tracks
+    pic = meta[5]
+    assert (pic["picture_type"], pic["mime_type"], pic["description"], pic["width"], pic["height"], pic["depth"], pic["colors"], pic["data"]) == \
+        (3, b"image/png", "cover ü".encode(), 4, 4, 24, 0, png)
+    assert meta[6]["length"] == 33
+    # default filter: STREAMINFO only; ignore_all: nothing at all
+    meta, si, _ = run(lambda d: None)
+    assert meta == [] and si is not None
+    meta, si, _ = run(lambda d: d.set_metadata_ignore_all())
+    assert meta == [] and si is None
+    # application ids invert the APPLICATION setting (:780-865)
+    meta, _, _ = run(lambda d: d.set_metadata_respond_application(b"bbbb"))
+    assert [(m["type"], m["id"]) for m in meta] == [(2, b"bbbb")]
+    meta, _, _ = run(lambda d: (d.set_metadata_respond(stream.META_APPLICATION), d.set_metadata_respond(stream.META_VORBIS_COMMENT), d.set_metadata_ignore_application(b"bbbb")))
+    assert [m["type"] for m in meta] == [2, 4] and meta[0]["id"] == b"aaaa"
