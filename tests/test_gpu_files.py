@@ -1,0 +1,158 @@
+"""GPU tests of the whole-file front end (include/flac_amd_files.h): .flac files byte for byte the
+ones the reference's flac tool writes from the same WAVE / AIFF / raw input with the same options,
+and decoded WAVE / AIFF files byte for byte the ones `flac -d` writes."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_bindings as ob
+from flac_amd import files, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(pcm, width, big=False, unsigned=False, shift=0):
+    x = (pcm.astype(np.int64) << shift)
+    if unsigned:
+        x = x + (1 << (8 * width - 1))
+    x = x & ((1 << (8 * width)) - 1)
+    b = np.zeros(x.shape + (width,), np.uint8)
+    for i in range(width):
+        b[..., (width - 1 - i) if big else i] = (x >> (8 * i)) & 255
+    return b.tobytes()
+
+
+def wave_bytes(pcm, rate, bps, container=None, extensible=False, mask=0, extra_chunks=b"", pad_fmt=False):
+    ch = pcm.shape[1]
+    container = container or ((bps + 7) // 8) * 8
+    width = container // 8
+    data = _pack(pcm, width, unsigned=container <= 8, shift=container - bps)
+    fmt = struct.pack("<HHIIHH", 65534 if extensible else 1, ch, rate, rate * ch * width, ch * width, container)
+    if extensible:
+        fmt += struct.pack("<HHI", 22, bps, mask) + b"\x01\x00\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+    elif pad_fmt:
+        fmt += struct.pack("<H", 0)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra_chunks + b"data" + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def aiff_bytes(pcm, rate, bps, offset=0):
+    ch = pcm.shape[1]
+    width = (bps + 7) // 8
+    data = _pack(pcm, width, big=True, shift=8 * width - bps)
+    sh = 0
+    while (rate >> (31 - sh)) == 0:
+        sh += 1
+    ext = struct.pack(">HII", 63 - (sh + 32) + 0x3FFF, (rate << sh) & 0xFFFFFFFF, 0)
+    comm = struct.pack(">HIH", ch, len(pcm), bps) + ext
+    ssnd = struct.pack(">II", offset, 0) + b"\xAA" * offset + data
+    body = b"AIFF" + b"ANNO" + struct.pack(">I", 3) + b"hi!\0" + b"COMM" + struct.pack(">I", 18) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd + (b"\0" if len(ssnd) & 1 else b"")
+    return b"FORM" + struct.pack(">I", len(body)) + body
+
+
+def _ref(args):
+    if not os.path.exists(ob.REF_FLAC):
+        pytest.skip("oracle/_ref/flac not built")
+    subprocess.run([ob.REF_FLAC, "--silent"] + [str(a) for a in args], check=True, timeout=180)
+
+
+CASES = {
+    "wav16-default": dict(kind="wav", seconds=23.0, ch=2, bps=16, rate=44100, level=5, tool=[], kw={}),
+    "wav16-8-verify-tags": dict(kind="wav", seconds=3.0, ch=2, bps=16, rate=44100, level=8, tool=["-V", "-T", "ARTIST=a", "-T", "TITLE=b c", "--padding=100", "-S", "1s", "-S", "X"],
+                                kw=dict(verify=True, tags=["ARTIST=a", "TITLE=b c"], padding=100, seekpoints="1s;X;")),
+    "wav8-mono": dict(kind="wav", seconds=1.5, ch=1, bps=8, rate=22050, level=3, tool=["--no-padding"], kw=dict(padding=0)),
+    "wav24-junk-chunks": dict(kind="wav", seconds=2.0, ch=2, bps=24, rate=96000, level=6, tool=["-S", "5x", "-b", "2048"], kw=dict(seekpoints="5x;", blocksize=2048),
+                              extra=b"LIST" + struct.pack("<I", 5) + b"abcde\0" + b"junk" + struct.pack("<I", 4) + b"1234", pad_fmt=True),
+    "wavext-6ch-24": dict(kind="wav", seconds=1.0, ch=6, bps=24, rate=48000, level=5, tool=["-S-"], kw=dict(seekpoints=""), extensible=True, mask=0x3f),
+    "wavext-20in24": dict(kind="wav", seconds=1.0, ch=2, bps=20, rate=48000, level=5, tool=["-T", "WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x9999", "-T", "A=b"],
+                          kw=dict(tags=["WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x9999", "A=b"]), extensible=True, mask=0, container=24),
+    "aiff16": dict(kind="aiff", seconds=2.5, ch=2, bps=16, rate=44100, level=7, tool=[], kw={}),
+    "aiff12-mono-offset": dict(kind="aiff", seconds=1.0, ch=1, bps=12, rate=32000, level=2, tool=["--lax"], kw=dict(lax=True), offset=6),
+    "raw16-be": dict(kind="raw", seconds=1.2, ch=2, bps=16, rate=48000, level=4, tool=["--force-raw-format", "--endian=big", "--sign=signed", "--channels=2", "--bps=16", "--sample-rate=48000", "-S", "100", "-S", "40000"],
+                     kw=dict(input_format=files.RAW, raw=dict(channels=2, bps=16, sample_rate=48000, big_endian=True), seekpoints="100;40000;")),
+    "raw8-unsigned": dict(kind="raw", seconds=0.7, ch=1, bps=8, rate=8000, level=0, tool=["--force-raw-format", "--endian=little", "--sign=unsigned", "--channels=1", "--bps=8", "--sample-rate=8000"],
+                          kw=dict(input_format=files.RAW, raw=dict(channels=1, bps=8, sample_rate=8000, unsigned=True))),
+}
+
+
+def _input(c):
+    n = int(c["seconds"] * c["rate"])
+    base = synth.music_like(c["seconds"] + 0.1, rate=c["rate"], seed=len(c["tool"]) + c["ch"])[:n]
+    cols = [base[:, i % 2].astype(np.int64) * (1 if i < 2 else (i + 1)) // (1 if i < 2 else 7) for i in range(c["ch"])]
+    pcm = np.stack(cols, axis=1)
+    pcm = (pcm << max(0, c["bps"] - 16)) >> max(0, 16 - c["bps"])
+    if c["kind"] == "wav":
+        return pcm, wave_bytes(pcm, c["rate"], c["bps"], container=c.get("container"), extensible=c.get("extensible", False), mask=c.get("mask", 0),
+                               extra_chunks=c.get("extra", b""), pad_fmt=c.get("pad_fmt", False)), "in.wav"
+    if c["kind"] == "aiff":
+        return pcm, aiff_bytes(pcm, c["rate"], c["bps"], offset=c.get("offset", 0)), "in.aiff"
+    width = c["bps"] // 8
+    return pcm, _pack(pcm, width, big=c["kw"]["raw"].get("big_endian", False), unsigned=c["kw"]["raw"].get("unsigned", False)), "in.raw"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_encoded_file_equals_the_reference_tools(gpu_engine, tmp_path, name):
+    c = CASES[name]
+    pcm, blob, fname = _input(c)
+    src = tmp_path / fname
+    src.write_bytes(blob)
+    want = tmp_path / "ref.flac"
+    _ref(["-%d" % c["level"]] + c["tool"] + ["-o", want, src])
+    got = tmp_path / "gpu.flac"
+    r = files.encode_file(src, got, level=c["level"], batch_frames=16, **c["kw"])
+    assert got.read_bytes() == want.read_bytes()
+    assert r["samples"] == len(pcm) and r["channels"] == c["ch"] and r["bits_per_sample"] == c["bps"] and r["bytes_written"] == want.stat().st_size
+
+
+@pytest.mark.parametrize("name", ["wav16-default", "wav8-mono", "wavext-6ch-24", "wavext-20in24", "aiff12-mono-offset", "wav24-junk-chunks"])
+@pytest.mark.parametrize("fmt", ["wave", "aiff"])
+def test_decoded_file_equals_the_reference_tools(gpu_engine, tmp_path, name, fmt):
+    c = CASES[name]
+    pcm, blob, fname = _input(c)
+    src = tmp_path / fname
+    src.write_bytes(blob)
+    flac = tmp_path / "x.flac"
+    files.encode_file(src, flac, level=c["level"], **c["kw"])
+    want = tmp_path / ("ref." + fmt)
+    _ref(["-d"] + (["--force-aiff-format"] if fmt == "aiff" else []) + ["-o", want, flac])
+    got = tmp_path / ("gpu." + fmt)
+    r = files.decode_file(flac, got, files.AIFF if fmt == "aiff" else files.WAVE)
+    assert got.read_bytes() == want.read_bytes()
+    assert r["samples"] == len(pcm) and r["md5_ok"]
+
+
+def test_unknown_length_stream_gets_its_header_fixed_up(gpu_engine, tmp_path):
+    """A stream whose STREAMINFO has no total (written to an unseekable sink): sizes are patched afterwards (decode.c:941-962)."""
+    from flac_amd import stream
+    n = 30000
+    pcm = synth.music_like(1.0, seed=3)[:n]
+    e = stream.MemoryEncoder(seekable=False)
+    assert e.set_compression_level(5) and e.init() == stream.INIT_OK and e.process_interleaved(pcm) and e.finish()
+    flac = tmp_path / "u.flac"
+    flac.write_bytes(bytes(e.buf))
+    want, got = tmp_path / "ref.wav", tmp_path / "gpu.wav"
+    _ref(["-d", "-o", want, flac])
+    r = files.decode_file(flac, got)
+    assert got.read_bytes() == want.read_bytes() and r["samples"] == n
+
+
+def test_raw_output_and_errors(gpu_engine, tmp_path):
+    pcm = synth.music_like(0.5, seed=4)[:20000]
+    src = tmp_path / "a.wav"
+    src.write_bytes(wave_bytes(pcm, 44100, 16))
+    flac = tmp_path / "a.flac"
+    files.encode_file(src, flac, level=1)
+    raw = tmp_path / "a.raw"
+    files.decode_file(flac, raw, files.RAW)
+    assert raw.read_bytes() == pcm.astype("<i2").tobytes()
+    bad = bytearray(flac.read_bytes())
+    bad[-100] ^= 0x55
+    (tmp_path / "bad.flac").write_bytes(bytes(bad))
+    with pytest.raises(files.FileError) as ei:
+        files.decode_file(tmp_path / "bad.flac", tmp_path / "bad.wav")
+    assert ei.value.code == -8
+    with pytest.raises(files.FileError):
+        files.encode_file(src, tmp_path / "b.flac", tags=["no equals sign"])

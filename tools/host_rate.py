@@ -48,3 +48,38 @@ for md5 in (1, 0):
     dt = time.perf_counter() - t0
     print("%-28s %d min: %.1f ms, %.1f MSamples/s (%d bytes out)" % ("stream object md5=%d" % md5, minutes, dt * 1e3, n / dt / 1e6, e.total))
     e.close()
+
+# whole files: WAVE on disk -> .flac on disk through the front end, against the reference tool on the same file
+import struct, subprocess, tempfile  # noqa: E402
+from flac_amd import files  # noqa: E402
+
+tmp = tempfile.mkdtemp(prefix="flacamd_rate_")
+wav = os.path.join(tmp, "in.wav")
+data = pcm16.tobytes()
+with open(wav, "wb") as f:
+    f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 176400, 4, 16) + b"data" + struct.pack("<I", len(data)))
+    f.write(data)
+for rep in range(2):
+    t0 = time.perf_counter()
+    r = files.encode_file(wav, os.path.join(tmp, "gpu.flac"), level=8, batch_frames=8192)
+    dt = time.perf_counter() - t0
+print("%-28s %d min: %.1f ms, %.1f MSamples/s (%d bytes out)" % ("encode_file wav->flac -8", minutes, dt * 1e3, n / dt / 1e6, r["bytes_written"]))
+t0 = time.perf_counter()
+r = files.decode_file(os.path.join(tmp, "gpu.flac"), os.path.join(tmp, "gpu.wav"))
+dt = time.perf_counter() - t0
+print("%-28s %d min: %.1f ms, %.1f MSamples/s" % ("decode_file flac->wav", minutes, dt * 1e3, n / dt / 1e6))
+assert open(os.path.join(tmp, "gpu.wav"), "rb").read()[44:] == data
+ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "flac")
+if os.path.exists(ref) and minutes <= 10:
+    t0 = time.perf_counter()
+    subprocess.run([ref, "--silent", "-f", "-8", "-o", os.path.join(tmp, "ref.flac"), wav], check=True)
+    dt = time.perf_counter() - t0
+    same = open(os.path.join(tmp, "ref.flac"), "rb").read() == open(os.path.join(tmp, "gpu.flac"), "rb").read()
+    print("%-28s %d min: %.1f ms, %.1f MSamples/s (identical file: %s)" % ("reference flac -8", minutes, dt * 1e3, n / dt / 1e6, same))
+    t0 = time.perf_counter()
+    subprocess.run([ref, "--silent", "-f", "-d", "-o", os.path.join(tmp, "ref.wav"), os.path.join(tmp, "ref.flac")], check=True)
+    dt = time.perf_counter() - t0
+    print("%-28s %d min: %.1f ms, %.1f MSamples/s" % ("reference flac -d", minutes, dt * 1e3, n / dt / 1e6))
+for fn in os.listdir(tmp):
+    os.remove(os.path.join(tmp, fn))
+os.rmdir(tmp)
