@@ -93,7 +93,7 @@ struct FaPackRec {
 struct FaWork {
 	// prep
 	uint8_t  *wasted;      // [G]
-	uint8_t  *is_const;    // [G]
+	uint8_t  *is_const;    // [G] bit 0: all samples equal; bit 1: every sample fits 16 bits (set by the 16-bit stereo preparation kernel only)
 	uint64_t *fixed_err;   // [5][G]
 	// autocorrelation
 	float    *autoc;       // [num_apod][lag][G]

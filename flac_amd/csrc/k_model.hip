@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 
 	CandWriter cw; cw.hdr = w.cand_hdr + fa_cand_idx(c, g, 0); cw.q = w.cand_q + fa_cand_idx(c, g, 0); cw.stride = c.cand_stride; cw.n = 0; cw.max_cand = c.max_cand;
 
-	const bool constant = (!c.disable_constant) && w.is_const[g];
+	const bool constant = (!c.disable_constant) && (w.is_const[g] & 1u);
 	if(n >= FA_MAX_FIXED_ORDER && !constant) {
 		// ---- fixed predictors (fixed.c:245-269, stream_encoder.c:3241-3293)
 		float fb[5]; unsigned long long e[5];

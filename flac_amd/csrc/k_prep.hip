@@ -144,6 +144,8 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 			if(i < n) {
 				const uint32_t a = (uint32_t)x[PP_HIST + q], b = (uint32_t)x[PP_HIST + q - 1], cc = (uint32_t)x[PP_HIST + q - 2], dd = (uint32_t)x[PP_HIST + q - 3], ee = (uint32_t)x[PP_HIST + q - 4];
 				o |= a; d |= (a != (uint32_t)x0) ? 1u : 0u;
+				// the side signal of 16-bit channels has 17 bits; bit 1 records a sample outside the 16-bit range
+				if(s == 3) d |= (((a ^ (uint32_t)((int32_t)a >> 31)) >> 15) != 0u) ? 2u : 0u;
 				if(i >= FA_MAX_FIXED_ORDER) { // fixed.c:229-243 sums start at the fifth sample
 					const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc), d3 = (int32_t)(a - 3u*b + 3u*cc - dd), d4 = (int32_t)(a - 4u*b + 6u*cc - 4u*dd + ee);
 					e0 += (uint32_t)(d0 < 0 ? -d0 : d0); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 		unsigned long long v = sh.err[s][k] >> wasted;
 		if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
 		w.fixed_err[(size_t)k * c.G + g] = v;
-		if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(sh.ne[s] ? 0 : 1); }
+		if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(((sh.ne[s] & 1u) ? 0u : 1u) | ((sh.ne[s] & 2u) ? 0u : 2u)); }   // bit 0: constant, bit 1: every sample fits 16 bits
 	}
 }
 

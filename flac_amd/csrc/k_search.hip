@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	const uint32_t verb_bits = 8u + wasted + n * bps;
 	uint32_t base_bits = (c.disable_verbatim && n >= FA_MAX_FIXED_ORDER) ? 0xffffffffu : verb_bits;
 	uint32_t type = FA_SUB_VERBATIM, est = base_bits;
-	const bool constant = (!c.disable_constant) && n >= FA_MAX_FIXED_ORDER && w.is_const[g];
+	const bool constant = (!c.disable_constant) && n >= FA_MAX_FIXED_ORDER && (w.is_const[g] & 1u);
 	if(constant) { const uint32_t cbits = 8u + wasted + bps; if(cbits < est) { type = FA_SUB_CONSTANT; est = cbits; } }
 	bool use_cand = false;
 	if(sh.have_best && ncand > 0 && sh.best_est < est) { use_cand = true; est = sh.best_est; }

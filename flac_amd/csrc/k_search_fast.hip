@@ -82,7 +82,8 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 	const uint32_t i0 = tid * SF_CH;
 	const uint32_t wasted = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.wasted[g]);
 	const uint32_t ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ncand[g]);
-	const uint32_t is_const = w.is_const[g];
+	const uint32_t sigflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.is_const[g]);   // bit 0: constant signal, bit 1: every sample fits 16 bits
+	const uint32_t is_const = sigflags & 1u;
 	const uint32_t bps = c.bps - wasted + ((c.midside && s == 3u) ? 1u : 0u);
 
 	// frame-level partition order range (stream_encoder.c:2934-2941); every block here is full length
@@ -104,9 +105,10 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 	uint8_t *kbuf = (uint8_t*)(cpo + cg);                              // [cg][64] Rice parameters at the candidate's best order
 
 	const bool active = i0 < n;
-	// samples and coefficients fit 16 bits: two taps per instruction (the side channel of a
-	// 16-bit stream has 17 bits and stays on the one-tap path)
-	const bool use_dot2 = bps <= 16u && !(c.debug & 0x8000u);
+	// samples and coefficients fit 16 bits: two taps per instruction.  The side channel of a 16-bit
+	// stream has 17 bits nominally; the preparation stage notes when its samples fit 16 bits anyway
+	// (left and right within 32767 of each other, the usual case)
+	const bool use_dot2 = (bps <= 16u || ((sigflags & 2u) && c.bps <= 16u && !(c.debug & 0x20000u))) && !(c.debug & 0x8000u);
 	const bool sad_on = sizeof(SUM) == 4 && !(c.debug & 0x4000u);
 
 	const uint32_t qrows = c.max_lpc_order ? c.max_lpc_order : 1u;
@@ -221,25 +223,60 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				const int4 *q4_ = (const int4*)(cq + (ci) * HIST); \
 				const int4 qa_ = q4_[0], qb_ = q4_[1], qc_ = q4_[2]; \
 				q[0] = qa_.x; q[1] = qa_.y; q[2] = qa_.z; q[3] = qa_.w; q[4] = qb_.x; q[5] = qb_.y; q[6] = qb_.z; q[7] = qb_.w; q[8] = qc_.x; q[9] = qc_.y; q[10] = qc_.z; q[11] = qc_.w; } while(0)
+			// ---- fixed predictors: the leading candidates (the model stage emits them first, ascending).  All
+			// five difference orders come out of one pass: d_k(i) = d_(k-1)(i) - d_(k-1)(i-1), and |d_k| is added
+			// up by the |a - b| + c instruction on the two order-(k-1) values (biased into unsigned order; the
+			// differences of samples of at most 25 bits stay far from wrapping).  Sample i < k has no order-k
+			// residual: those go to separate sums that the frame's first thread drops.
+			uint32_t nfixed = 0;
+			while(nfixed < gn && FA_CAND_KIND(chdr[nfixed]) == 0) nfixed++;
+			if(nfixed) {
+				SUM fT[5], fH[5];
+#pragma unroll
+				for(int k = 0; k < 5; k++) { fT[k] = 0; fH[k] = 0; }
+				const uint32_t B = 0x80000000u;
+				auto add_abs = [&](SUM &acc, uint32_t a, uint32_t b) {
+					if(sad_on) acc = (SUM)sad_u32(a ^ B, b ^ B, (uint32_t)acc);
+					else acc += abs_u32((int32_t)(a - b));
+				};
+				uint32_t px = (uint32_t)xw[HIST - 1], pd1, pd2, pd3;
+				{
+					const uint32_t x2 = (uint32_t)xw[HIST - 2], x3 = (uint32_t)xw[HIST - 3], x4 = (uint32_t)xw[HIST - 4];
+					const uint32_t e1 = x2 - x3, e2 = x3 - x4;      // d1(-2), d1(-3)
+					pd1 = px - x2;
+					const uint32_t g2 = e1 - e2;                      // d2(-2)
+					pd2 = pd1 - e1;
+					pd3 = pd2 - g2;
+				}
+#pragma unroll
+				for(int j = 0; j < SF_CH; j++) {
+					const uint32_t a = (uint32_t)xw[HIST + j];
+					const uint32_t d1 = a - px, d2 = d1 - pd1, d3 = d2 - pd2;
+					add_abs(fT[0], a, 0u);
+					add_abs(j < 1 ? fH[1] : fT[1], a, px);
+					add_abs(j < 2 ? fH[2] : fT[2], d1, pd1);
+					add_abs(j < 3 ? fH[3] : fT[3], d2, pd2);
+					add_abs(j < 4 ? fH[4] : fT[4], d3, pd3);
+					px = a; pd1 = d1; pd2 = d2; pd3 = d3;
+				}
+				for(uint32_t ci = 0; ci < nfixed; ci++) {
+					const uint32_t order = FA_CAND_ORDER(chdr[ci]);
+					SUM vT = fT[4], vH = fH[4];
+					if(order == 0u) { vT = fT[0]; vH = 0; } else if(order == 1u) { vT = fT[1]; vH = fH[1]; } else if(order == 2u) { vT = fT[2]; vH = fH[2]; } else if(order == 3u) { vT = fT[3]; vH = fH[3]; }
+					atomicAdd(&psum[(size_t)ci * SF_ROW + part], vT + (tid >= 1u ? vH : (SUM)0));
+				}
+			}
 			if(use_dot2) {
 				// packed pairs xp[t] = (x[t], x[t-1]); the unpacked history is dead from here on
 				uint32_t xp[SF_W];
 				xp[0] = 0;
 #pragma unroll
 				for(int j = 1; j < SF_W; j++) xp[j] = pack_lo16(xw[j], xw[j - 1]);
-				for(uint32_t ci = 0; ci < gn; ci++) {
+				for(uint32_t ci = nfixed; ci < gn; ci++) {
 					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
 					accT = 0; accH = 0; accM = 0;
-					if(FA_CAND_KIND(hdr) == 0) {
-						// the differences need 4 samples of history: unpack them from the pairs rather than keep
-						// the unpacked window alive through the loop
-						int32_t xf[SF_W];
-#pragma unroll
-						for(int j = 0; j < SF_W; j++) xf[j] = j >= HIST - 4 ? (int32_t)(int16_t)(xp[j] & 0xffffu) : 0;
-						fixed_each_dispatch(order, xf, by_residual);
-					}
-					else if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
+					if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
 					else {
 						uint32_t qp[HIST / 2];
 						const uint2 *q2 = (const uint2*)(cqp + ci * (HIST / 2));
@@ -252,12 +289,11 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				}
 			}
 			else {
-				for(uint32_t ci = 0; ci < gn; ci++) {
+				for(uint32_t ci = nfixed; ci < gn; ci++) {
 					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
 					accT = 0; accH = 0; accM = 0;
-					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, by_residual);
-					else {
+					{
 						int32_t q[HIST];
 						SF_LOAD_Q(ci, q);
 						if(!LIGHT && FA_CAND_WIDE(hdr)) lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs);

@@ -37,3 +37,7 @@ tot = t[ok, 7] - t[ok, 0]
 print("  %-26s mean %8.0f  median %8.0f" % ("whole workgroup", tot.mean(), np.median(tot)))
 span = t[ok].max() - t[ok].min()
 print("  span of sampled WGs: %d ticks" % span)
+sig = np.arange(len(t)) % 4
+for k, nm in enumerate(["left", "right", "mid", "side"]):
+    m = ok & (sig == k)
+    print("  signal %-5s MAC mean %8.0f  whole %8.0f" % (nm, dt[m, 1].mean(), tot[m[ok]].mean() if False else (t[m, 7] - t[m, 0]).mean()))
