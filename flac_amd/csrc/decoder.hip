@@ -313,49 +313,59 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			const uint32_t po = br.read(4), plen = method ? 5u : 4u, esc = method ? 31u : 15u;
 			if(po == 0) { if(n < order) { ok = false; break; } } else if((n >> po) < order) { ok = false; break; } // :2732-2745
 			if(po > 0 && ((n >> po) << po) != n) { ok = false; break; }
-			uint32_t i = order;
-			for(uint32_t part = 0; part < (1u << po) && ok; part++) {
-				uint32_t cnt = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
-				const uint32_t k = br.read(plen);
-				uint32_t raw = 0;
-				const bool escaped = k >= esc;
-				if(escaped) raw = br.read(5);
-				for(; cnt > 0; cnt--, i++) {
-					int32_t r;
-					if(!escaped) {
-						const uint32_t qv = br.read_unary();
-						const uint32_t low = k ? br.read(k) : 0u;
-						const uint32_t u = (qv << k) | low;
-						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-					}
-					else r = br.read_signed(raw);
-					int32_t x;
-					if(in_regs) {
-						if(wide) {
-							long long sum = 0;
+			// One flat loop over the samples of the subframe: the lanes of a wave hold frames with different
+			// partition orders, and nested partition / sample loops would run (most partitions) x (longest
+			// partition) iterations for all of them.  Here every lane advances one sample per iteration and
+			// reads its next partition header when the current partition runs out.
+			uint32_t i = order, left = 0, part = 0, k = 0, raw = 0;
+			bool escaped = false;
+			while(i < n) {
+				if(left == 0) {
+					left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
+					part++;
+					k = br.read(plen);
+					escaped = k >= esc;
+					if(escaped) raw = br.read(5);
+					if(br.err) { ok = false; break; }
+					if(left == 0) continue;   // first partition as long as the predictor order: no residual in it
+				}
+				int32_t r;
+				if(!escaped) {
+					const uint32_t qv = br.read_unary();
+					const uint32_t low = k ? br.read(k) : 0u;
+					const uint32_t u = (qv << k) | low;
+					r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+				}
+				else r = br.read_signed(raw);
+				int32_t x;
+				if(in_regs) {
+					if(wide) {
+						long long sum = 0;
 #pragma unroll
-							for(int j = 0; j < FD_REGORD; j++) sum += (long long)qr[j] * (long long)hr[j];
-							x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift));
-						}
-						else {
-							uint32_t sum = 0;
-#pragma unroll
-							for(int j = 0; j < FD_REGORD; j++) sum += (uint32_t)qr[j] * (uint32_t)hr[j];
-							x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift));
-						}
-#pragma unroll
-						for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
-						hr[0] = x;
+						for(int j = 0; j < FD_REGORD; j++) sum += (long long)qr[j] * (long long)hr[j];
+						x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift));
 					}
 					else {
-						if(wide) { long long sum = 0; for(uint32_t j = 0; j < order; j++) sum += (long long)s_q[j][lane] * (long long)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift)); }
-						else { uint32_t sum = 0; for(uint32_t j = 0; j < order; j++) sum += (uint32_t)s_q[j][lane] * (uint32_t)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift)); }
-						s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
+						uint32_t sum = 0;
+#pragma unroll
+						for(int j = 0; j < FD_REGORD; j++) sum += (uint32_t)qr[j] * (uint32_t)hr[j];
+						x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift));
 					}
-					out[i] = (int32_t)((uint32_t)x << wasted);
-					if(br.err) { ok = false; break; }
+#pragma unroll
+					for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
+					hr[0] = x;
 				}
+				else {
+					if(wide) { long long sum = 0; for(uint32_t j = 0; j < order; j++) sum += (long long)s_q[j][lane] * (long long)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift)); }
+					else { uint32_t sum = 0; for(uint32_t j = 0; j < order; j++) sum += (uint32_t)s_q[j][lane] * (uint32_t)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift)); }
+					s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
+				}
+				out[i] = (int32_t)((uint32_t)x << wasted);
+				if(br.err) { ok = false; break; }
+				i++; left--;
 			}
+			if(!ok) break;
+			if(part == 0) { const uint32_t k0 = br.read(plen); if(k0 >= esc) (void)br.read(5); }   // order == blocksize: the one partition is empty, its header is still there
 		}
 		else { ok = false; break; }                                                       // reserved subframe types :2494, :2505
 		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
