@@ -48,7 +48,7 @@ struct FdWork {
 	uint64_t *sample_off;   // [max_frames] first wide sample of the r-th accepted frame
 	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
 	const uint16_t *crc_tab;   // [256] CRC-16 byte table
-	const uint16_t *crc_segmul;// [64] x^(8 * crc_seg_bytes * j)
+	const uint16_t *crc_segmul;// [256] x^(8 * crc_seg_bytes * j)
 };
 
 // ---- header parsing shared by the scan and the decode kernels
@@ -384,34 +384,76 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 	w.cand_info[ci] = info;
 }
 
-// CRC-16 over every parsed candidate, one 64-thread workgroup per candidate
-__global__ void __launch_bounds__(64) fd_crc_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
+// CRC-16 over every parsed candidate, one workgroup per candidate.  The frame is cut into FD_CRC_THREADS
+// segments of crc_seg_bytes counted back from its end; every thread fetches its segment as aligned words
+// (all loads in flight before the first use), runs it through a four-bytes-per-step table scheme, multiplies
+// its remainder by x^(8 * bytes that follow it) and the remainders are XORed.  Leading zero bytes do not
+// change a CRC that starts at zero, so the one segment that sticks out in front of the frame is padded with zeros.
+#define FD_CRC_THREADS 256
+#define FD_CRC_MAXWORDS 16   // segments of up to 64 bytes stay in registers (frames up to 16 KB); longer ones take the byte loop
+__global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
-	__shared__ uint16_t tab[256];
+	__shared__ uint16_t tab[4][256];   // tab[k][b]: remainder of byte b followed by k zero bytes
+	__shared__ uint32_t s_x[FD_CRC_THREADS / 64];
 	const uint32_t ci = blockIdx.x, tid = threadIdx.x;
 	const uint32_t info = w.cand_info[ci];
 	if(!(info & 1u)) return;
-	for(uint32_t i = tid; i < 256; i += 64) tab[i] = w.crc_tab[i];
+	{
+		uint32_t v = w.crc_tab[tid];
+		tab[0][tid] = (uint16_t)v;
+		const uint16_t *t0 = w.crc_tab;
+#pragma unroll
+		for(int k = 1; k < 4; k++) { v = ((v << 8) & 0xffffu) ^ t0[v >> 8]; tab[k][tid] = (uint16_t)v; }
+	}
 	__syncthreads();
 	const uint64_t pos = w.cand_pos[ci], end = w.cand_end[ci];
 	const uint64_t len = end - pos;
-	const uint64_t seg = c.crc_seg_bytes;
+	const uint32_t seg = c.crc_seg_bytes;   // a multiple of 4
 	uint32_t crc = 0;
-	if(len <= seg * 64u) {
-		const uint64_t e1 = (seg * tid < len) ? len - seg * tid : 0u, b0 = (e1 > seg) ? e1 - seg : 0u;
-		if(e1 > 0) {
-			for(uint64_t i = b0; i < e1; i++) crc = ((crc << 8) & 0xffffu) ^ tab[(crc >> 8) ^ bytes[pos + i]];
-			// multiply by x^(8 * seg * tid)
-			uint32_t m = w.crc_segmul[tid], r = 0;
-			for(int i = 15; i >= 0; i--) { r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu; if((m >> i) & 1u) r ^= crc; }
-			crc = r;
-		}
+	const bool fits = len <= (uint64_t)seg * FD_CRC_THREADS;
+	if(fits && (uint64_t)seg * tid < len) {
+		const uint64_t e1 = len - (uint64_t)seg * tid;            // frame offset just past this thread's segment
+		const long long start = (long long)e1 - (long long)seg;    // may lie before the frame
+		if(start >= 0 && seg <= 4u * FD_CRC_MAXWORDS) {
+			// aligned words covering [pos + start, pos + start + seg): seg / 4 + 1 of them
+			const uint64_t a = pos + (uint64_t)start, a0 = a & ~(uint64_t)3;
+			const uint32_t sh = (uint32_t)(a & 3u) * 8u, nw = seg / 4u;
+			uint32_t wv[FD_CRC_MAXWORDS + 1];
 #pragma unroll
-		for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
+			for(int j = 0; j <= FD_CRC_MAXWORDS; j++) {
+				wv[j] = 0;
+				if((uint32_t)j <= nw) {
+					const uint64_t o = a0 + 4u * (uint32_t)j;
+					if(o + 4u <= c.nbytes) wv[j] = *(const uint32_t*)(bytes + o);
+					else { for(uint32_t m = 0; m < 4u; m++) if(o + m < c.nbytes) wv[j] |= (uint32_t)bytes[o + m] << (8u * m); }
+				}
+			}
+#pragma unroll
+			for(int j = 0; j < FD_CRC_MAXWORDS; j++) {
+				if((uint32_t)j < nw) {
+					const uint32_t x = sh ? (wv[j] >> sh) | (wv[j + 1] << (32u - sh)) : wv[j];   // bytes in stream order, lowest first
+					crc = (uint32_t)tab[3][((crc >> 8) ^ x) & 0xffu] ^ (uint32_t)tab[2][(crc ^ (x >> 8)) & 0xffu] ^ (uint32_t)tab[1][(x >> 16) & 0xffu] ^ (uint32_t)tab[0][x >> 24];
+				}
+			}
+		}
+		else {
+			for(long long i = start < 0 ? 0 : start; i < (long long)e1; i++) crc = ((crc << 8) & 0xffffu) ^ tab[0][(crc >> 8) ^ bytes[pos + (uint64_t)i]];
+		}
+		// multiply by x^(8 * seg * tid)
+		uint32_t m = w.crc_segmul[tid], r = 0;
+		for(int i = 15; i >= 0; i--) { r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu; if((m >> i) & 1u) r ^= crc; }
+		crc = r;
 	}
-	else crc = 1; // longer than any frame this stream can hold
+#pragma unroll
+	for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
+	if((tid & 63u) == 0) s_x[tid >> 6] = crc;
+	__syncthreads();
 	// the CRC of a frame including its own CRC-16 field is zero
-	if(tid == 0 && crc == 0) w.cand_info[ci] = info | 2u;
+	if(tid == 0) {
+		uint32_t all = 0;
+		for(uint32_t k = 0; k < FD_CRC_THREADS / 64; k++) all ^= s_x[k];
+		if(fits && all == 0) w.cand_info[ci] = info | 2u;
+	}
 }
 
 // Accept CRC-valid candidates, check that they tile the range, number them, prefix-sum samples
@@ -532,14 +574,14 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	c.ws_stride = ((max_blocksize + 63u) & ~63u) + 64u;
 	// longest possible frame: header + per channel (head + verbatim-sized body with one spare bit per sample) + footer
 	const size_t max_frame_bytes = 16 + (size_t)channels * (((size_t)max_blocksize * (bits_per_sample + 2) + 7) / 8 + 64) + 2;
-	c.crc_seg_bytes = (uint32_t)((max_frame_bytes + 63) / 64);
+	c.crc_seg_bytes = (uint32_t)(((max_frame_bytes + 255) / 256 + 3) & ~(size_t)3);   // per thread of the CRC kernel, whole words
 	FD_TRY(hipSetDevice(device));
 	const size_t nwg = (max_bytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES;
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = fd_align(off + bytes); return o; };
 	const size_t o_cnt = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
 		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * c.ws_stride * 4),
-		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(1024);
+		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(2048);
 	d->arena_bytes = off;
 	hipError_t he = hipMalloc(&d->arena, off);
 	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
@@ -548,9 +590,9 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	w.wg_count = (uint32_t*)(b + o_cnt); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
 	w.cand_info = (uint32_t*)(b + o_info); w.cand_bs = (uint32_t*)(b + o_bs); w.cand_num = (uint64_t*)(b + o_num); w.ws = (int32_t*)(b + o_ws);
 	w.frame_of = (uint32_t*)(b + o_fo); w.sample_off = (uint64_t*)(b + o_so); w.result = (uint64_t*)(b + o_res);
-	uint16_t tab[256 + 64];
+	uint16_t tab[256 + 256];
 	for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }
-	{ unsigned v = 1; for(unsigned j = 0; j < 64; j++) { tab[256 + j] = (uint16_t)v; for(unsigned z = 0; z < c.crc_seg_bytes; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]; } }
+	{ unsigned v = 1; for(unsigned j = 0; j < 256; j++) { tab[256 + j] = (uint16_t)v; for(unsigned z = 0; z < c.crc_seg_bytes; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]; } }
 	he = hipMemcpy(b + o_tab, tab, sizeof tab, hipMemcpyHostToDevice);
 	if(he != hipSuccess) { hipFree(d->arena); free(d); return FLACAMD_E_DEVICE; }
 	w.crc_tab = (const uint16_t*)(b + o_tab); w.crc_segmul = (const uint16_t*)(b + o_tab) + 256;
@@ -590,7 +632,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	if(ncand == 0) return FLACAMD_E_BAD_STREAM;
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
 	hipLaunchKernelGGL(fd_decode_kernel, dim3((ncand + 63u) / 64u), dim3(64), 0, st, bytes, c, d->work);
-	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(64), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
 	hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);
 	FD_TRY(hipGetLastError());
