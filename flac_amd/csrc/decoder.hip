@@ -162,40 +162,67 @@ __global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w
 
 // ---- speculative decode, one lane per candidate
 
+#define FD_RING_WORDS 64u   // per-lane window of the stream kept in LDS, in 32-bit words
+#define FD_LOW_WORDS 24u    // top up when any lane of the wave has fewer words than this ahead of it
 struct BitReader {
-	// The stream is consumed through a 64-bit window refilled 32 bits at a time from a 16-byte chunk
-	// held in registers; the chunk after it is always already requested, so a lane never waits a
-	// full memory round trip in the middle of a token (a lane owns its frame: nobody else fetches
-	// these bytes for it).
-	const uint8_t *b; uint64_t nbytes, widx, bitpos; unsigned long long buf; uint32_t avail; bool err;
-	uint4 cur, nxt; uint64_t cur_chunk;   // chunk index (16-byte units) held in cur; nxt holds cur_chunk + 1
+	// The stream is consumed through a 64-bit register window refilled 32 bits at a time from a per-lane
+	// ring of words in LDS (column `lane` of ring[][64]).  The ring is topped up by top_up(), which the
+	// decode loop calls at a point all lanes of the wave pass together: memory latency is then paid once
+	// per 64 bytes for the whole wave.  (Fetching on demand inside the token readers made every lane's
+	// fetch a wait for all lanes: a wave-wide wait for the newest load on nearly every iteration.)
+	const uint8_t *b; uint64_t nbytes, widx, wr, bitpos; unsigned long long buf; uint32_t avail; bool err;
+	uint32_t (*ring)[64]; uint32_t lane;
 	__device__ __forceinline__ uint4 load_chunk(uint64_t ck) const
 	{
 		const uint64_t off = ck * 16u;
 		if(off + 16u <= nbytes) return *(const uint4*)(b + off);
 		uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;   // tail of the buffer: byte by byte, never past the end
+		if(off < nbytes) {
 #pragma unroll
-		for(uint32_t k = 0; k < 4u; k++) {
-			if(off + k < nbytes) v0 |= (uint32_t)b[off + k] << (8u * k);
-			if(off + 4u + k < nbytes) v1 |= (uint32_t)b[off + 4u + k] << (8u * k);
-			if(off + 8u + k < nbytes) v2 |= (uint32_t)b[off + 8u + k] << (8u * k);
-			if(off + 12u + k < nbytes) v3 |= (uint32_t)b[off + 12u + k] << (8u * k);
+			for(uint32_t k = 0; k < 4u; k++) {
+				if(off + k < nbytes) v0 |= (uint32_t)b[off + k] << (8u * k);
+				if(off + 4u + k < nbytes) v1 |= (uint32_t)b[off + 4u + k] << (8u * k);
+				if(off + 8u + k < nbytes) v2 |= (uint32_t)b[off + 8u + k] << (8u * k);
+				if(off + 12u + k < nbytes) v3 |= (uint32_t)b[off + 12u + k] << (8u * k);
+			}
 		}
 		return make_uint4(v0, v1, v2, v3);
 	}
+	__device__ __forceinline__ void store_chunk(uint64_t at, const uint4 &v)
+	{
+		const uint32_t r = (uint32_t)at & (FD_RING_WORDS - 1u);   // `at` is a multiple of 4
+		ring[r][lane] = v.x; ring[r + 1u][lane] = v.y; ring[r + 2u][lane] = v.z; ring[r + 3u][lane] = v.w;
+	}
+	// wave-uniform call site: 64 more bytes for every lane that has room, when any lane runs low
+	__device__ __forceinline__ void top_up()
+	{
+		const uint32_t ahead = (uint32_t)(wr - widx);
+		if(__any(ahead < FD_LOW_WORDS ? 1 : 0)) {
+			if(ahead + 16u <= FD_RING_WORDS) {
+				const uint64_t ck = wr >> 2;
+				const uint4 v0 = load_chunk(ck), v1 = load_chunk(ck + 1u), v2 = load_chunk(ck + 2u), v3 = load_chunk(ck + 3u);
+				store_chunk(wr, v0); store_chunk(wr + 4u, v1); store_chunk(wr + 8u, v2); store_chunk(wr + 12u, v3);
+				wr += 16u;
+			}
+		}
+	}
 	__device__ __forceinline__ uint32_t load_word(uint64_t wi)
 	{
-		const uint64_t ck = wi >> 2;
-		if(ck != cur_chunk) { cur = nxt; cur_chunk = ck; nxt = load_chunk(ck + 1u); }
-		const uint32_t sel = (uint32_t)wi & 3u;
-		const uint32_t v = sel == 0u ? cur.x : sel == 1u ? cur.y : sel == 2u ? cur.z : cur.w;
-		return __builtin_bswap32(v);
+		if(wi >= wr) { store_chunk(wr, load_chunk(wr >> 2)); wr += 4u; }   // ran dry between two top-ups (a very long token): fetch alone
+		return __builtin_bswap32(ring[(uint32_t)wi & (FD_RING_WORDS - 1u)][lane]);
 	}
 	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)load_word(widx++) << (32u - avail); avail += 32u; } }
-	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos)
+	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos, uint32_t (*ring_)[64], uint32_t lane_)
 	{
 		b = base; nbytes = nb; widx = pos >> 2; buf = 0; avail = 0; err = false; bitpos = (pos >> 2) * 32u;
-		cur_chunk = widx >> 2; cur = load_chunk(cur_chunk); nxt = load_chunk(cur_chunk + 1u);
+		ring = ring_; lane = lane_;
+		wr = widx & ~(uint64_t)3;
+		{
+			const uint64_t ck = wr >> 2;
+			const uint4 v0 = load_chunk(ck), v1 = load_chunk(ck + 1u), v2 = load_chunk(ck + 2u), v3 = load_chunk(ck + 3u);
+			store_chunk(wr, v0); store_chunk(wr + 4u, v1); store_chunk(wr + 8u, v2); store_chunk(wr + 12u, v3);
+			wr += 16u;
+		}
 		refill();
 		const uint32_t skip = (uint32_t)(pos & 3u) * 8u;
 		buf <<= skip; avail -= skip; bitpos += skip;
@@ -243,6 +270,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 	// any mix of per-lane row indices stays bank-conflict free
 	__shared__ int32_t s_q[FD_RING][64];
 	__shared__ int32_t s_h[FD_RING][64];
+	__shared__ uint32_t s_ring[FD_RING_WORDS][64];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t ci = blockIdx.x * 64u + lane;
 	const uint32_t ncand = w.ncand[0] < c.max_frames ? w.ncand[0] : c.max_frames;
@@ -253,7 +281,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 	w.cand_end[ci] = pos; w.cand_bs[ci] = 0; w.cand_num[ci] = 0;
 	if(!fd_parse_header(bytes, c.nbytes, pos, c, h)) { w.cand_info[ci] = 0; return; }
 	const uint32_t n = h.blocksize;
-	BitReader br; br.init(bytes, c.nbytes, pos + h.hdr_bytes);
+	BitReader br; br.init(bytes, c.nbytes, pos + h.hdr_bytes, s_ring, lane);
 	bool ok = true;
 	for(uint32_t ch = 0; ch < h.channels && ok; ch++) {
 		uint32_t bps = h.bps;
@@ -265,7 +293,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 		if(head & 1u) { wasted = br.read_unary() + 1u; if(wasted >= bps) { ok = false; break; } bps -= wasted; }
 		head &= 0xfeu;
 		if(head == 0) { const int32_t v = br.read_signed(bps) << wasted; for(uint32_t i = 0; i < n; i++) out[i] = v; }     // constant :2526
-		else if(head == 2) { for(uint32_t i = 0; i < n; i++) out[i] = br.read_signed(bps) << wasted; }                    // verbatim :2698
+		else if(head == 2) { for(uint32_t i = 0; i < n; i++) { br.top_up(); out[i] = br.read_signed(bps) << wasted; } }                    // verbatim :2698
 		else if((head >= 16 && head <= 24) || head >= 64) {
 			const bool lpc = head >= 64;
 			const uint32_t order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
@@ -280,6 +308,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			const bool in_regs = order <= (uint32_t)FD_REGORD;
 			uint32_t hp = 0;
 			for(uint32_t i = 0; i < order; i++) {
+				br.top_up();
 				const int32_t v = br.read_signed(bps);
 				out[i] = v << wasted;
 				s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
@@ -295,7 +324,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 				const int32_t sh = br.read_signed(5);
 				if(sh < 0) { ok = false; break; }     // never produced by the reference encoder (lpc.c:225-260); shifting by a negative count is undefined there
 				shift = (uint32_t)sh;
-				for(uint32_t j = 0; j < order; j++) s_q[j][lane] = br.read_signed(prec);
+				for(uint32_t j = 0; j < order; j++) { br.top_up(); s_q[j][lane] = br.read_signed(prec); }
 				// back through the lane's own LDS column with fixed indices (an indexed register array
 				// would be placed in scratch memory)
 #pragma unroll
@@ -320,6 +349,7 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			uint32_t i = order, left = 0, part = 0, k = 0, raw = 0;
 			bool escaped = false;
 			while(i < n) {
+				br.top_up();
 				if(left == 0) {
 					left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
 					part++;
