@@ -11,6 +11,7 @@
 // repeats), a few dozen bytes out.
 #include "engine_types.h"
 #include "wave_ops.h"
+#include "residual.h"
 
 __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 {
@@ -126,6 +127,12 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 	__syncthreads();
 
 	uint32_t sums[4][5], orv[4], ne[4];
+	// Full blocks whose threads all hold 16 samples: every difference order comes from the one below
+	// (d_k(i) = d_(k-1)(i) - d_(k-1)(i-1)) and |d_k| is added up by the |a - b| + c instruction on the two
+	// order-(k-1) values, biased into unsigned order (differences of 17-bit samples are far from wrapping).
+	// The first four samples of a frame do not count (fixed.c:229-243): the frame's first thread takes its
+	// share back out afterwards.  Anything else (a short last block) goes sample by sample below.
+	const bool whole = n == c.N && (n % PP_CH) == 0;
 #pragma unroll
 	for(int s = 0; s < 4; s++) {
 		const int32_t ca = (s == 1) ? 0 : 1, cb = (s == 0) ? 0 : (s == 3 ? -1 : 1);
@@ -138,18 +145,58 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 		}
 		const int32_t x0 = (ca * (int32_t)(int16_t)(first & 0xffffu) + cb * ((int32_t)first >> 16)) >> sh1;
 		uint32_t o = 0, d = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+		if(whole) {
+			if(i0 < n) {
+				const uint32_t B = 0x80000000u;
+				uint32_t diff = 0, mag = 0;
+				uint32_t pxb = (uint32_t)x[3] ^ B, pd1, pd2, pd3;
+				{
+					const uint32_t h1 = (uint32_t)x[3], h2 = (uint32_t)x[2], h3 = (uint32_t)x[1], h4 = (uint32_t)x[0];
+					const uint32_t a1 = h1 - h2, a2 = h2 - h3, a3 = h3 - h4;   // d1(-1), d1(-2), d1(-3)
+					const uint32_t b1 = a1 - a2, b2 = a2 - a3;                  // d2(-1), d2(-2)
+					pd1 = a1 ^ B; pd2 = b1 ^ B; pd3 = (b1 - b2) ^ B;
+				}
 #pragma unroll
-		for(int q = 0; q < PP_CH; q++) {
-			const uint32_t i = i0 + (uint32_t)q;
-			if(i < n) {
-				const uint32_t a = (uint32_t)x[PP_HIST + q], b = (uint32_t)x[PP_HIST + q - 1], cc = (uint32_t)x[PP_HIST + q - 2], dd = (uint32_t)x[PP_HIST + q - 3], ee = (uint32_t)x[PP_HIST + q - 4];
-				o |= a; d |= (a != (uint32_t)x0) ? 1u : 0u;
-				// the side signal of 16-bit channels has 17 bits; bit 1 records a sample outside the 16-bit range
-				if(s == 3) d |= (((a ^ (uint32_t)((int32_t)a >> 31)) >> 15) != 0u) ? 2u : 0u;
-				if(i >= FA_MAX_FIXED_ORDER) { // fixed.c:229-243 sums start at the fifth sample
-					const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc), d3 = (int32_t)(a - 3u*b + 3u*cc - dd), d4 = (int32_t)(a - 4u*b + 6u*cc - 4u*dd + ee);
-					e0 += (uint32_t)(d0 < 0 ? -d0 : d0); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
-					e3 += (uint32_t)(d3 < 0 ? -d3 : d3); e4 += (uint32_t)(d4 < 0 ? -d4 : d4);
+				for(int q = 0; q < PP_CH; q++) {
+					const uint32_t a = (uint32_t)x[PP_HIST + q], ab = a ^ B;
+					const uint32_t d1b = (ab - pxb) ^ B, d2b = (d1b - pd1) ^ B, d3b = (d2b - pd2) ^ B;   // the biases cancel in each difference
+					e0 = sad_u32(ab, B, e0); e1 = sad_u32(ab, pxb, e1); e2 = sad_u32(d1b, pd1, e2); e3 = sad_u32(d2b, pd2, e3); e4 = sad_u32(d3b, pd3, e4);
+					o |= a; diff |= a ^ (uint32_t)x0;
+					if(s == 3) mag |= a ^ (uint32_t)((int32_t)a >> 31);
+					pxb = ab; pd1 = d1b; pd2 = d2b; pd3 = d3b;
+				}
+				// bit 0: differs from the first sample somewhere; bit 1 (side signal of 16-bit channels, nominally 17 bits): a sample outside the 16-bit range
+				d = (diff ? 1u : 0u) | ((s == 3 && (mag >> 15)) ? 2u : 0u);
+				if(tid == 0) {
+					// samples 0..3 of the frame: history is zero, so d_k(q) is the k-th difference of (0, 0, 0, 0, x0, x1, x2, x3)
+					const uint32_t s0 = (uint32_t)x[4], s1 = (uint32_t)x[5], s2 = (uint32_t)x[6], s3 = (uint32_t)x[7];
+					const uint32_t f1[4] = { s0, s1 - s0, s2 - s1, s3 - s2 };
+					const uint32_t f2[4] = { f1[0], f1[1] - f1[0], f1[2] - f1[1], f1[3] - f1[2] };
+					const uint32_t f3[4] = { f2[0], f2[1] - f2[0], f2[2] - f2[1], f2[3] - f2[2] };
+					const uint32_t f4[4] = { f3[0], f3[1] - f3[0], f3[2] - f3[1], f3[3] - f3[2] };
+					auto mg = [](uint32_t v) { const int32_t t = (int32_t)v; return (uint32_t)(t < 0 ? -t : t); };
+					e0 -= mg(s0) + mg(s1) + mg(s2) + mg(s3);
+					e1 -= mg(f1[0]) + mg(f1[1]) + mg(f1[2]) + mg(f1[3]);
+					e2 -= mg(f2[0]) + mg(f2[1]) + mg(f2[2]) + mg(f2[3]);
+					e3 -= mg(f3[0]) + mg(f3[1]) + mg(f3[2]) + mg(f3[3]);
+					e4 -= mg(f4[0]) + mg(f4[1]) + mg(f4[2]) + mg(f4[3]);
+				}
+			}
+		}
+		else {
+#pragma unroll
+			for(int q = 0; q < PP_CH; q++) {
+				const uint32_t i = i0 + (uint32_t)q;
+				if(i < n) {
+					const uint32_t a = (uint32_t)x[PP_HIST + q], b = (uint32_t)x[PP_HIST + q - 1], cc = (uint32_t)x[PP_HIST + q - 2], dd = (uint32_t)x[PP_HIST + q - 3], ee = (uint32_t)x[PP_HIST + q - 4];
+					o |= a; d |= (a != (uint32_t)x0) ? 1u : 0u;
+					// the side signal of 16-bit channels has 17 bits; bit 1 records a sample outside the 16-bit range
+					if(s == 3) d |= (((a ^ (uint32_t)((int32_t)a >> 31)) >> 15) != 0u) ? 2u : 0u;
+					if(i >= FA_MAX_FIXED_ORDER) { // fixed.c:229-243 sums start at the fifth sample
+						const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc), d3 = (int32_t)(a - 3u*b + 3u*cc - dd), d4 = (int32_t)(a - 4u*b + 6u*cc - 4u*dd + ee);
+						e0 += (uint32_t)(d0 < 0 ? -d0 : d0); e1 += (uint32_t)(d1 < 0 ? -d1 : d1); e2 += (uint32_t)(d2 < 0 ? -d2 : d2);
+						e3 += (uint32_t)(d3 < 0 ? -d3 : d3); e4 += (uint32_t)(d4 < 0 ? -d4 : d4);
+					}
 				}
 			}
 		}
