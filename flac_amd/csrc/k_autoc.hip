@@ -67,11 +67,24 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 		return r;
 	};
 
+	// Lags are handled two at a time with the packed multiply and add instructions (two independent
+	// IEEE operations each, unfused: same results as the scalar ones).  The pair (d[t], d[t-1]) that the
+	// lags (k, k+1) of a sample need must sit in one aligned register pair, whatever the parity of t: the
+	// windowed samples are therefore kept twice, paired (even, odd) and (odd, even), which costs one copy
+	// per sample instead of re-aligning the whole delay line.
+	typedef float f2 __attribute__((ext_vector_type(2)));
+	constexpr int H = (LAG - 1 + 1) & ~1;      // history kept between steps, even
+	constexpr int NP = LAG / 2;                // lag pairs (0,1), (2,3), ...; an odd LAG leaves lag LAG-1 on its own
+	constexpr int T = H + AC_STEP;             // time slots of a step: t = H + j for sample j
 	for(uint32_t a = 0; a < c.num_apod; a++) {
 		const float *__restrict__ win = w.window + (size_t)a * c.N;
-		float acc[LAG], hist[LAG];
+		f2 A[NP > 0 ? NP : 1];
+		float alast = 0.0f;
+		f2 E[T / 2], O[T / 2];                  // E[i] = (d[2i], d[2i+1]), O[i] = (d[2i+1], d[2i+2])
 #pragma unroll
-		for(int l = 0; l < LAG; l++) { acc[l] = 0.0f; hist[l] = 0.0f; }
+		for(int i = 0; i < NP; i++) A[i] = (f2){0.0f, 0.0f};
+#pragma unroll
+		for(int i = 0; i < T / 2; i++) { E[i] = (f2){0.0f, 0.0f}; O[i] = (f2){0.0f, 0.0f}; }
 		Raw16 nxt = load16(0);
 		for(uint32_t i0 = 0; i0 < nloop; i0 += AC_STEP) {
 			const Raw16 cur = nxt;
@@ -85,19 +98,35 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 				// lpc.c:60; samples past the end of a short block are zero (raw is zero there and the
 				// window index is clamped to stay inside the table)
 				const float d = __fmul_rn((float)x, win[i]);
-#pragma unroll
-				for(int k = LAG - 1; k > 0; k--) hist[k] = hist[k-1];
-				hist[0] = d;
+				constexpr int dummy = 0; (void)dummy;
+				const int t = H + j;
+				if(t & 1) E[t / 2].y = d; else E[t / 2].x = d;
+				if((t - 1) & 1) O[(t - 1) / 2].y = d; else O[(t - 1) / 2].x = d;
+				const f2 dd = (f2){d, d};
 				// autoc[l] += d[m-l] * d[m]  (same products, same order as lpc.c:100-109; the
 				// zero-filled history adds +-0 for m < l, which leaves the sum unchanged)
 #pragma unroll
-				for(int k = 0; k < LAG; k++) acc[k] = __fadd_rn(acc[k], __fmul_rn(hist[k], d));
+				for(int q = 0; q < NP; q++) {
+					const int m = t - 2 * q;                          // d[m], d[m-1] for lags 2q, 2q+1
+					const f2 pr = (m & 1) ? E[(m - 1) / 2] : O[(m - 2) / 2];   // (d[m-1], d[m])
+					A[q] = A[q] + __builtin_shufflevector(pr, pr, 1, 0) * dd;
+				}
+				if(LAG & 1) {
+					const int m = t - (LAG - 1);
+					const float hv = (m & 1) ? E[m / 2].y : E[m / 2].x;
+					alast = __fadd_rn(alast, __fmul_rn(hv, d));
+				}
 			}
+			// the last H slots become the history of the next step
+#pragma unroll
+			for(int i = 0; i < H / 2; i++) { E[i] = E[i + AC_STEP / 2]; O[i] = O[i + AC_STEP / 2]; }
 		}
 		if(active) {
 #pragma unroll
-			for(int k = 0; k < LAG; k++)
-				if((uint32_t)k < c.lag) w.autoc[((size_t)a * c.lag + k) * c.G + g] = acc[k];
+			for(int k = 0; k < LAG; k++) {
+				const float v = (k == LAG - 1 && (LAG & 1)) ? alast : ((k & 1) ? A[k / 2].y : A[k / 2].x);
+				if((uint32_t)k < c.lag) w.autoc[((size_t)a * c.lag + k) * c.G + g] = v;
+			}
 		}
 	}
 }
