@@ -31,7 +31,7 @@
 #define SF_WAVES (SF_THREADS / 64)
 #define SF_PARTS 64u     // finest partitions one wave prices: partition orders up to 6
 #define SF_LEVELS 7
-#define SF_ROW 128u      // entries of a candidate's row of partition sums: all orders, finest first
+#define SF_ROW 64u       // entries of a candidate's row of partition sums (finest order)
 
 __device__ __forceinline__ uint32_t sf_limit_po(uint32_t limit, uint32_t blocksize, uint32_t order) // format.c:548-561
 {
@@ -310,61 +310,62 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		__syncthreads();
 		SF_STAMP(3);
 
-		// ---- one wave per candidate: sums of every partition order by in-register doubling steps,
-		// then every lane prices two partitions (its finest one, and one of the 2^maxpo - 1 coarser
-		// ones, fetched through the candidate's LDS row), bits per order, best order (searched
-		// max -> min, strict '<'), subframe estimate
-		const uint32_t per = 2u * parts0, per_log = maxpo_f + 1u;
+		// ---- one wave per candidate.  Sums of every partition order by in-register doubling steps: after
+		// step l every lane holds the sum of its aligned block of 2^l finest partitions.  Every lane prices
+		// two partitions: its finest one (level 0) and, for lane L != 0, block L >> lv of level lv = ctz(L) + 1,
+		// whose sum it picks up as the chain passes that level (each block of each level has exactly one such
+		// lane: 63 coarser partitions for 63 lanes, nothing goes through memory).  Bits per order: the
+		// level-lv lanes are the lanes congruent to 2^(lv-1) modulo 2^lv, so one butterfly over the
+		// distances 32 .. 1 walks lane 0 through the totals of levels 6, 6+5, ... 6+..+1.  Then the best
+		// order (searched max -> min, strict '<') and the subframe estimate.
+		const uint32_t lvB = lane ? (uint32_t)__ffs((int)lane) : 7u;          // level of this lane's second partition (lane 0: none)
+		const bool hasB = lane != 0u && lane < parts0;
+		const uint32_t pB = hasB ? lane >> lvB : 0u;                           // its index among the partitions of that level
+		const uint32_t poA = maxpo_f, poB = hasB ? maxpo_f - lvB : 0u;
 		for(uint32_t ci = wave; ci < ((c.debug & 2u) ? 0u : gn); ci += SF_WAVES) {
-			const uint32_t hdr = chdr[ci], info = cinfo[ci];
+			// the same for every lane: keep them in scalar registers, so that what depends on them branches without masks
+			const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)chdr[ci]), info = (uint32_t)__builtin_amdgcn_readfirstlane((int)cinfo[ci]);
 			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
 			const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
 			const uint32_t lvl_c = maxpo_f - maxpo_c;
-			SUM *row = psum + (size_t)ci * SF_ROW;
+			const SUM *row = psum + (size_t)ci * SF_ROW;
 			SUM vA = (lane < parts0) ? row[lane] : (SUM)0;
 			// a value at the candidate's own finest order is wrapped to 32 bits when the reference's
 			// accumulator there is 32 bits wide; coarser orders add the wrapped values
 			if(narrow_c && lvl_c == 0u) vA &= (SUM)0xffffffffull;
-			SUM v = vA;
-#pragma unroll
-			for(int l = 1; l < SF_LEVELS; l++) {
-				if((uint32_t)l <= maxpo_f) {
-					switch(l) {
-					case 1: v = block_sum_step<1>(v); break; case 2: v = block_sum_step<2>(v); break; case 3: v = block_sum_step<3>(v); break;
-					case 4: v = block_sum_step<4>(v); break; case 5: v = block_sum_step<5>(v); break; default: v = block_sum_step<6>(v); break;
-					}
-					if(narrow_c && (uint32_t)l == lvl_c) v &= (SUM)0xffffffffull;
-					// the first lane of every aligned block of 2^l files the block's sum: orders are laid out
-					// finest first (parts0 entries), then parts0/2, ... as in the general kernel
-					if((lane & ((1u << l) - 1u)) == 0 && lane < parts0) row[per - (per >> l) + (lane >> l)] = v;
-				}
-			}
-			// second item of this lane: entry parts0 + lane of the row (the last lane has none)
-			const uint32_t idxB = parts0 + lane;
-			const bool hasB = lane + 1u < parts0;
-			const SUM vB = hasB ? row[idxB] : (SUM)0;
-			const uint32_t lB = hasB ? per_log - (32u - (uint32_t)__clz((int)(per - idxB - 1u))) : 7u;
-			const uint32_t pB = idxB - (per - (per >> lB));
-			const uint32_t poA = maxpo_f, poB = maxpo_f - (lB < 7u ? lB : 0u);
+			SUM v = vA, vB = 0;
+			// (levels above the frame's finest order only add the zeros of the unused lanes: harmless, and cheaper than branching)
+#define SF_CHAIN(L) do { v = block_sum_step<L>(v); if(narrow_c && lvl_c == (uint32_t)(L)) v &= (SUM)0xffffffffull; if(lvB == (uint32_t)(L)) vB = v; } while(0)
+			SF_CHAIN(1); SF_CHAIN(2); SF_CHAIN(3); SF_CHAIN(4); SF_CHAIN(5); SF_CHAIN(6);
+#undef SF_CHAIN
 			uint32_t kA, estA, kB, estB;
 			sf_price<SUM>(vA, (n >> poA) - (lane == 0 ? order : 0u), poA == 0, FA_CAND_K(hdr), c.k_limit, kA, estA);   // order 0 takes the suggested parameter, stream_encoder.c:3982-4029
 			sf_price<SUM>(vB, (n >> poB) - (pB == 0 ? order : 0u), poB == 0, FA_CAND_K(hdr), c.k_limit, kB, estB);
 			if(!(lane < parts0 && poA <= maxpo_c && poA >= minpo_c)) estA = 0;
 			if(!(hasB && poB <= maxpo_c && poB >= minpo_c)) estB = 0;
-			uint32_t tot[8];
+			// level totals: run[j] = bits of levels 6, 6+5, ... down to level 6 - j (read from lane 0 after each step)
+			uint32_t run[6], tA = estA, tB = estB;
+#define SF_TOT(D, J) do { tA = class_sum_step<D>(tA); tB = class_sum_step<D>(tB); run[J] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tB); } while(0)
+			SF_TOT(32, 0); SF_TOT(16, 1); SF_TOT(8, 2); SF_TOT(4, 3); SF_TOT(2, 4); SF_TOT(1, 5);
+#undef SF_TOT
+			const uint32_t totA = (uint32_t)__builtin_amdgcn_readfirstlane((int)tA);
+			// bits of level lv (partition order maxpo_f - lv); orders are tried from the candidate's highest down, strict '<'
+			const uint32_t lvbits[7] = { totA, run[5] - run[4], run[4] - run[3], run[3] - run[2], run[2] - run[1], run[1] - run[0], run[0] };
+			const uint32_t lv_lo = maxpo_f - maxpo_c, lv_hi = maxpo_f - minpo_c;
+			uint32_t best = 0, bestlv = 0; bool have = false;
 #pragma unroll
-			for(int j = 0; j < 8; j++) tot[j] = (j == 0 ? estA : 0u) + (lB == (uint32_t)j ? estB : 0u);
-			wave_combine<8, false>(tot, lane);   // lane l: bits of level l >> 3
-			uint32_t best = 0, bestpo = 0; bool have = false;
-			for(int po = (int)maxpo_c; po >= (int)minpo_c; po--) {
-				const uint32_t b = 6u + (uint32_t)__builtin_amdgcn_readlane((int)tot[0], (int)((maxpo_f - (uint32_t)po) * 8u));
-				if(!have || b < best) { best = b; bestpo = (uint32_t)po; have = true; }
+			for(int lv = 0; lv < 7; lv++) {
+				if((uint32_t)lv >= lv_lo && (uint32_t)lv <= lv_hi) {
+					const uint32_t b = 6u + lvbits[lv];
+					if(!have || b < best) { best = b; bestlv = (uint32_t)lv; have = true; }
+				}
 			}
+			const uint32_t bestpo = maxpo_f - bestlv;
 			uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
 			if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
 			// park the parameters of the best order: entry p of the row is partition p
 			const uint32_t bl = maxpo_f - bestpo;
-			const bool own_b = bl == 0u ? (lane < parts0) : (hasB && lB == bl);
+			const bool own_b = bl == 0u ? (lane < parts0) : (hasB && lvB == bl);
 			const uint32_t kb = bl == 0u ? kA : kB;
 			if(own_b) kbuf[(size_t)ci * SF_PARTS + (bl == 0u ? lane : pB)] = (uint8_t)kb;
 			const uint32_t big = __any((own_b && kb >= 15u) ? 1 : 0) ? 1u : 0u;

@@ -50,6 +50,22 @@ __device__ __forceinline__ unsigned long long block_sum_step(unsigned long long 
 	return v + (((unsigned long long)phi << 32) | plo);
 }
 
+// One step of a butterfly that gathers residue classes: v plus the value of a lane D lanes away
+// (a lane of the same class modulo D; every lane of that class holds the same value by then).  Applied
+// for D = 32, 16, 8, 4, 2, 1 in that order, lane L holds after the step for D the sum over all lanes
+// congruent to L modulo D; lane 0 therefore runs through the sums of the multiples of 32, 16, ... 1.
+template<int D>
+__device__ __forceinline__ uint32_t class_sum_step(uint32_t v)
+{
+	static_assert(D == 1 || D == 2 || D == 4 || D == 8 || D == 16 || D == 32, "distance");
+	if(D == 32) { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return r[0] + r[1]; }
+	if(D == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return r[0] + r[1]; }
+	if(D == 8) return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+	if(D == 4) return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+	if(D == 2) return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
+}
+
 // Sum (or OR) NV = 2^m values across the 64 lanes of a wave with a halving butterfly: every
 // exchange step halves the number of values a lane still carries (about NV exchanges instead
 // of 6 * NV).  Afterwards lane l holds the total of value (l >> (6 - m)) in v[0].
