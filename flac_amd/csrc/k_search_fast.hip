@@ -272,8 +272,12 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				xp[0] = 0;
 #pragma unroll
 				for(int j = 1; j < SF_W; j++) xp[j] = pack_lo16(xw[j], xw[j - 1]);
+				// |x - pred| with both sides moved into unsigned order by 2^(31 - shift): the sums start from 2^31, so that
+				// a logical shift yields pred + 2^(31 - shift) directly, and the samples carry the same offset, which is
+				// redone only when the shift differs from the previous candidate's (|x| < 2^15 and shift <= 15 keep x + offset positive)
+				uint32_t xs[SF_CH], xs_shift = 0xffffffffu;
 				for(uint32_t ci = nfixed; ci < gn; ci++) {
-					const uint32_t hdr = chdr[ci];
+					const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)chdr[ci]);
 					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
 					accT = 0; accH = 0; accM = 0;
 					if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
@@ -282,7 +286,19 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 						const uint2 *q2 = (const uint2*)(cqp + ci * (HIST / 2));
 						const uint2 pa = q2[0], pb = q2[1], pc = q2[2];
 						qp[0] = pa.x; qp[1] = pa.y; qp[2] = pb.x; qp[3] = pb.y; qp[4] = pc.x; qp[5] = pc.y;
-						if(sad_on && shift >= 1u) lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_sad);
+						if(sad_on && shift >= 1u) {
+							if(shift != xs_shift) {
+								const uint32_t off = 1u << (31u - shift);
+#pragma unroll
+								for(int j = 0; j < SF_CH; j++) xs[j] = (xb[j] ^ 0x80000000u) + off;
+								xs_shift = shift;
+							}
+							auto by_sum = [&](int sidx, int32_t sum, int P) {
+								const uint32_t pb = (uint32_t)sum >> shift;
+								if(sidx + SF_CH < P) accM = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accH); else accT = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accT);
+							};
+							lpc_sum_each_dot2_dispatch(order, xp, qp, (int32_t)0x80000000u, by_sum);
+						}
 						else lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_abs);
 					}
 					deposit(ci);

@@ -97,6 +97,19 @@ __device__ __forceinline__ void lpc_pred_each_dot2(const int32_t (&xw)[W], const
 	}
 }
 
+// the same sums handed over unshifted, starting from `init`: f(s, sum, P)
+template<int P, int W, class F>
+__device__ __forceinline__ void lpc_sum_each_dot2(const uint32_t (&xp)[W], const uint32_t (&qp)[HIST / 2], int32_t init, F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < W - HIST; s++) {
+		int32_t acc = init;
+#pragma unroll
+		for(int m = 0; m < (P + 1) / 2; m++) acc = dot2_i16(qp[m], xp[HIST + s - 1 - 2 * m], acc);
+		f(s, acc, P);
+	}
+}
+
 #define RESIDUAL_ORDER_SWITCH(order, CALL) \
 	switch(order) { \
 	case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
@@ -114,6 +127,14 @@ template<int W, class F>
 __device__ __forceinline__ void lpc_pred_each_dot2_dispatch(uint32_t order, const int32_t (&xw)[W], const uint32_t (&xp)[W], const uint32_t (&qp)[HIST / 2], uint32_t shift, F &&f)
 {
 #define RESIDUAL_CALL(P) lpc_pred_each_dot2<P>(xw, xp, qp, shift, f)
+	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
+#undef RESIDUAL_CALL
+}
+
+template<int W, class F>
+__device__ __forceinline__ void lpc_sum_each_dot2_dispatch(uint32_t order, const uint32_t (&xp)[W], const uint32_t (&qp)[HIST / 2], int32_t init, F &&f)
+{
+#define RESIDUAL_CALL(P) lpc_sum_each_dot2<P>(xp, qp, init, f)
 	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
 #undef RESIDUAL_CALL
 }
