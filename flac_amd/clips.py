@@ -2,12 +2,11 @@
 every clip becomes a complete FLAC stream, byte-identical to what the reference's encoder
 writes for it.
 
-Clips are grouped by (channels, bits per sample, sample rate): one engine encoder per group,
-sized for the group's longest clip and reused; the clips of a group are uploaded in ONE copy,
-back to back in device memory; each clip is one engine call on that resident buffer (frames of
-one clip are a frame range like any other: frame numbers restart at 0, the last block may be
-short); the MD5 of every clip of the group comes from one launch of the on-device MD5 kernel
-(one lane per clip), so the serial-per-stream digest does not serialise the batch.
+Clips are grouped by (channels, bits per sample, sample rate).  The clips of a group are laid out
+back to back in whole blocks, uploaded in ONE copy and coded by ONE engine call
+(flacamd_encode_streams_device: frame numbers restart at 0 for every clip, every clip's last block
+may be short); the MD5 of every clip of the group comes from one launch of the on-device MD5 kernel
+(one lane per clip) on a stream of its own, so the serial-per-stream digest overlaps the encode.
 """
 import numpy as np
 
@@ -41,46 +40,44 @@ def encode_clips(clips, level=5, device=0):
         fmt, dt = (engine.PCM_S16, np.int16) if bps <= 16 else (engine.PCM_S32, np.int32)
         item = np.dtype(dt).itemsize * ch
         lens = [clips[i][0].shape[0] for i in members]
-        # every clip starts on a 16-byte boundary of the shared buffer: the vector-load kernels require it
-        align = 16 // item if 16 % item == 0 else 16
+        # every clip starts on a block boundary of the shared buffer: frame f of the batch is samples [f * bs, f * bs + bs)
+        nfr = [-(-n // bs) for n in lens]
         starts, pos = [], 0
-        for n in lens:
+        for f in nfr:
             starts.append(pos)
-            pos += -(-n // align) * align
+            pos += f * bs
         host = np.zeros((pos, ch), dtype=dt)
         for i, st, n in zip(members, starts, lens):
             host[st:st + n] = clips[i][0]
         d_pcm = torch.from_numpy(host).to(dev)
-        offs = []   # the alignment gaps between clips are hashed as streams of their own and dropped
+        offs = []   # the padding between clips is hashed as streams of its own and dropped
         for st, n in zip(starts, lens):
             offs += [st, st + n]
+        offs.append(pos)
         side = torch.cuda.Stream(device=dev)
         fut = pool.submit(engine.md5_device, d_pcm.data_ptr(), fmt, ch, bps, offs, device, side.cuda_stream)
-        plans.append((ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side))
-    # ---- phase 2: one engine call per clip on the resident buffers; outputs stay on the device
+        plans.append((ch, bps, rate, members, params, bs, fmt, lens, starts, nfr, d_pcm, fut, side))
+    # ---- phase 2: one engine call per group on the resident buffer; outputs stay on the device until the call returns
     results = []
-    for ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side in plans:
-        nfr = [-(-n // bs) for n in lens]
-        enc = engine.Encoder(params, max_frames=max(nfr), device=device)
-        caps = [enc.max_output_bytes(f) for f in nfr]
-        d_out = torch.empty(sum(caps), dtype=torch.uint8, device=dev)
-        d_fb = torch.empty(sum(nfr), dtype=torch.int32, device=dev)
-        totals, o_off, f_off = [], 0, 0
-        for st, n, f, cap in zip(starts, lens, nfr, caps):
-            totals.append(enc.encode_device(d_pcm.data_ptr() + st * item, fmt, n, d_out.data_ptr() + o_off, cap, d_fb.data_ptr() + 4 * f_off, final=True, first_frame=0))
-            o_off += cap
-            f_off += f
+    for ch, bps, rate, members, params, bs, fmt, lens, starts, nfr, d_pcm, fut, side in plans:
+        total_frames = sum(nfr)
+        enc = engine.Encoder(params, max_frames=total_frames, device=device)
+        cap = enc.max_output_bytes(total_frames)
+        d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_fb = torch.empty(total_frames, dtype=torch.int32, device=dev)
+        total = enc.encode_streams_device(d_pcm.data_ptr(), fmt, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
         enc.close()
-        results.append((d_out.cpu().numpy(), d_fb.cpu().numpy(), totals, caps, nfr))
+        results.append((d_out[:total].cpu().numpy(), d_fb.cpu().numpy()))
     # ---- phase 3: digests, stream heads, assembly
-    for (ch, bps, rate, members, params, bs, fmt, item, lens, starts, d_pcm, fut, side), (h_out, h_fb, totals, caps, nfr) in zip(plans, results):
+    for (ch, bps, rate, members, params, bs, fmt, lens, starts, nfr, d_pcm, fut, side), (h_out, h_fb) in zip(plans, results):
         digests = fut.result()[::2]
         o_off = f_off = 0
         for k, i in enumerate(members):
             sizes = h_fb[f_off:f_off + nfr[k]]
+            nbytes = int(sizes.sum())
             head = engine.stream_head(bs, int(sizes.min()), int(sizes.max()), rate, ch, bps, lens[k], digests[k])
-            out[i] = head + h_out[o_off:o_off + totals[k]].tobytes()
-            o_off += caps[k]
+            out[i] = head + h_out[o_off:o_off + nbytes].tobytes()
+            o_off += nbytes
             f_off += nfr[k]
     pool.shutdown()
     return out

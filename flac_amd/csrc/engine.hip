@@ -257,7 +257,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
+		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
 	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
@@ -266,7 +266,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
-	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.window = (const float*)(b + o_window);
+	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
 	{
@@ -330,6 +330,8 @@ extern "C" int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6])
 	return FLACAMD_OK;
 }
 
+static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st);
+
 extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
 	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream)
@@ -350,6 +352,13 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 	c.last_n = (uint32_t)(nsamples - (F64 - 1) * N);
 	c.last_fractional = (final_block && c.last_n != N) ? 1u : 0u;
 	c.first_frame = first_frame_number; c.prev_assignment = prev_assignment;
+	c.multi = 0; c.skip_full = 0;
+	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
+}
+
+// The stages of one batch on stream st; synchronises once at the end to read the status word and the total.
+static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st)
+{
 	e->last_F = c.F; e->last_G = c.G;
 
 	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
@@ -388,6 +397,48 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 	if(status & 1u) return FLACAMD_E_FRAME_OVERFLOW;
 	if(status & 2u) return FLACAMD_E_CAPACITY;
 	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nstreams,
+	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream)
+{
+	if(!e || !d_pcm || !d_out || nstreams == 0 || !h_start || !h_len) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && e->p.bits_per_sample > 16) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t N = e->cfg.N;
+	// frame f of the batch starts at sample f * N: the streams must tile the buffer in whole blocks
+	uint64_t F64 = 0;
+	for(uint32_t i = 0; i < nstreams; i++) {
+		if(h_len[i] == 0 || h_start[i] != F64 * N) return FLACAMD_E_INVALID_ARGUMENT;
+		F64 += (h_len[i] + N - 1) / N;
+		if(F64 > e->max_frames) return FLACAMD_E_CAPACITY;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	HIP_TRY(hipSetDevice(e->device));
+	uint32_t *tab = (uint32_t*)malloc(sizeof(uint32_t) * 2u * (size_t)F64);
+	if(!tab) return FLACAMD_E_OUT_OF_MEMORY;
+	{
+		uint32_t f = 0;
+		for(uint32_t i = 0; i < nstreams; i++) {
+			const uint64_t nf = (h_len[i] + N - 1) / N;
+			for(uint64_t k = 0; k < nf; k++, f++) {
+				tab[f] = (k + 1 == nf) ? (uint32_t)(h_len[i] - k * N) : N;
+				tab[F64 + f] = (uint32_t)k;
+			}
+		}
+	}
+	hipError_t he = hipMemcpyAsync(e->work.frame_len, tab, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st);
+	if(he == hipSuccess) he = hipMemcpyAsync(e->work.frame_num, tab + F64, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st);
+	if(he == hipSuccess) he = hipStreamSynchronize(st);   // the table is pageable host memory: done with it before it is freed
+	free(tab);
+	if(he != hipSuccess) return hip_fail(he, "hipMemcpyAsync(frame tables)");
+
+	FaCfg c = e->cfg;
+	c.pcm_format = (uint32_t)pcm_format;
+	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
+	c.last_n = N; c.last_fractional = 0; c.first_frame = 0; c.prev_assignment = 0;
+	c.multi = 1; c.skip_full = 0;
+	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
 }
 
 extern "C" int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,

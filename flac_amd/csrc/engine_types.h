@@ -27,6 +27,8 @@ struct FaCfg {
 	uint32_t F;               // frames in this batch
 	uint32_t last_n;          // samples in the last frame of the batch
 	uint32_t last_fractional; // last frame is the short final block of the stream
+	uint32_t multi;           // the batch holds several complete streams: frame lengths and numbers come from FaWork::frame_len / frame_num
+	uint32_t skip_full;       // general search kernel: full-length frames are left to the register-resident kernel
 	uint32_t first_frame;     // frame number of frame 0 of the batch
 	uint32_t prev_assignment;
 	uint32_t max_lpc_order, qlp_precision, prec_search, exhaustive;
@@ -112,6 +114,8 @@ struct FaWork {
 	FaPackRec *packrec;    // [F] (mono / stereo fast path)
 	uint32_t *status;      // [1] nonzero = some frame overflowed its slot
 	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
+	uint32_t *frame_len;   // [F] samples per frame, multi-stream batches only
+	uint32_t *frame_num;   // [F] frame number within its stream, multi-stream batches only
 	const float *window;   // [num_apod][N]
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial
@@ -122,7 +126,11 @@ struct FaWork {
 #include <hip/hip_runtime.h>
 
 // number of samples in frame f of the batch
-__device__ __forceinline__ uint32_t fa_frame_len(const FaCfg &c, uint32_t f) { return (f + 1 == c.F) ? c.last_n : c.N; }
+__device__ __forceinline__ uint32_t fa_frame_len(const FaCfg &c, const FaWork &w, uint32_t f) { return c.multi ? w.frame_len[f] : ((f + 1 == c.F) ? c.last_n : c.N); }
+// frame number coded in its header (streams of a multi-stream batch each start at 0)
+__device__ __forceinline__ uint32_t fa_frame_num(const FaCfg &c, const FaWork &w, uint32_t f) { return c.multi ? w.frame_num[f] : c.first_frame + f; }
+// the short final block of a stream: coded with partition order 0 (stream_encoder.c:2934)
+__device__ __forceinline__ bool fa_frame_fractional(const FaCfg &c, const FaWork &w, uint32_t f) { return c.multi ? w.frame_len[f] != c.N : (f + 1 == c.F && c.last_fractional); }
 
 // Sample `i` of channel `ch` of the wide-sample stream starting at batch sample 0.
 __device__ __forceinline__ int32_t fa_pcm(const void *pcm, uint32_t fmt, uint32_t channels, uint64_t wide, uint32_t ch)

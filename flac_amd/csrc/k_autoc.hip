@@ -43,10 +43,10 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const bool active = g < c.G;
 	const uint32_t gg = active ? g : c.G - 1u;
 	const uint32_t f = gg >> 2, s = gg & 3u;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
 	const uint32_t f0 = (blockIdx.x * 64u) >> 2;
-	const uint32_t nloop = (f0 + 1 == c.F) ? c.last_n : c.N;
+	const uint32_t nloop = (!c.multi && f0 + 1 == c.F) ? c.last_n : c.N;   // short frames in between: their lanes add zeros past their end
 	// signal = (ca * left + cb * right) >> cs: L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), wasted bits left in
 	const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
 	const uint32_t sh = s == 2u ? 1u : 0u;
@@ -140,11 +140,11 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 	const bool active = g < c.G;
 	const uint32_t gg = active ? g : c.G - 1u;
 	const uint32_t f = gg / c.nsig, s = gg - f * c.nsig;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	// lanes are in frame order, so if the first lane sits in the last frame all lanes do
 	const uint32_t f0 = (blockIdx.x * 64u) / c.nsig;
-	const uint32_t nloop = (f0 + 1 == c.F) ? c.last_n : c.N;
+	const uint32_t nloop = (!c.multi && f0 + 1 == c.F) ? c.last_n : c.N;   // short frames in between: their lanes add zeros past their end
 
 	for(uint32_t a = 0; a < c.num_apod; a++) {
 		const float *__restrict__ win = w.window + (size_t)a * c.N;

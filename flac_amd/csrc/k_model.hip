@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 	const uint32_t g = blockIdx.x * 64u + threadIdx.x;
 	if(g >= c.G) return;
 	const uint32_t f = g / c.nsig, s = g - f * c.nsig;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint32_t wasted = w.wasted[g];
 	const uint32_t bps = c.bps - wasted + ((c.midside && s == 3u) ? 1u : 0u);
 

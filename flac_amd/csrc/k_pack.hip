@@ -118,7 +118,7 @@ __device__ __forceinline__ uint32_t fa_assignment(const FaCfg &c, const FaWork &
 {
 	uint32_t a = 0;
 	if(c.midside) {
-		const uint32_t fa = c.first_frame + f;
+		const uint32_t fa = fa_frame_num(c, w, f);
 		const uint32_t cnt = c.loose ? fa % c.loose_period : 0u;
 		// frame whose four estimates decide: this one, or the first of its decision period
 		uint32_t decide_ok = 1, fd = f;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 	uint32_t *bitbuf = (uint32_t*)(xs + xs_words_for(c.N));     // [bitbuf_words]
 
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	uint32_t *slot_words = (uint32_t*)(w.slots + (size_t)f * c.slot_bytes);
 	uint8_t *slot = w.slots + (size_t)f * c.slot_bytes;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 		w.assignment[f] = a;
 
 		// ---- frame header (stream_encoder_framing.c:219-364), built by one lane
-		const uint32_t nb = fa_frame_header(c, n, c.first_frame + f, a, [&](uint32_t i, uint32_t byte) { bitbuf[i >> 2] |= byte << (24u - 8u * (i & 3u)); });
+		const uint32_t nb = fa_frame_header(c, n, fa_frame_num(c, w, f), a, [&](uint32_t i, uint32_t byte) { bitbuf[i >> 2] |= byte << (24u - 8u * (i & 3u)); });
 		sh.hdr_bytes = nb;
 	}
 	__syncthreads();
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	uint32_t *bitbuf = (uint32_t*)lds_raw;
 
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	uint8_t *slot = w.slots + (size_t)f * c.slot_bytes;
 	uint32_t *slot_words = (uint32_t*)slot;
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 		const uint32_t e = i0 / (c.N >> kspread);
 		kpre[sc] = rec->k[sc][e < FA_MAX_PARTS ? e : FA_MAX_PARTS - 1u];
 	}
-	const FrameHdrFields hf = fa_frame_header_fields(c, n, c.first_frame + f);
+	const FrameHdrFields hf = fa_frame_header_fields(c, n, fa_frame_num(c, w, f));
 
 	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels
 	int32_t xa[PF_W], xb[PF_W];
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 
 	// ---- frame header (one lane of the last wave), subframe heads (token-parallel, first wave)
 	if(tid == PF_THREADS - 1u) {
-		fa_frame_header(c, n, c.first_frame + f, a, [&](uint32_t i, uint32_t byte) { atomicOr(&bitbuf[i >> 2], byte << (24u - 8u * (i & 3u))); });
+		fa_frame_header(c, n, fa_frame_num(c, w, f), a, [&](uint32_t i, uint32_t byte) { atomicOr(&bitbuf[i >> 2], byte << (24u - 8u * (i & 3u))); });
 	}
 	if(tid < 32u * NSUB && !(c.debug & 0x40u)) {
 		const uint32_t sc = tid >> 5, t = tid & 31u;

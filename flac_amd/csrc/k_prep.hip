@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 	__shared__ unsigned long long s_err[5];
 
 	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;
 
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 {
 	__shared__ PrepFastShared sh;
 	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
 	const uint32_t i0 = tid * PP_CH;
 	if(tid < 20u) sh.err[tid / 5u][tid % 5u] = 0;

@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	__shared__ SearchShared sh;
 
 	const uint32_t g = blockIdx.x + g0, f = g / c.nsig, s = g - f * c.nsig;   // g0: first signal of the range this launch covers
-	const uint32_t n = fa_frame_len(c, f);
+	const uint32_t n = fa_frame_len(c, w, f);
+	if(c.skip_full && n == c.N) return;   // coded by the register-resident kernel
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wasted = w.wasted[g];
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 
 	// frame-level partition order range (stream_encoder.c:2934-2941)
 	uint32_t maxpo_f;
-	if(f + 1 == c.F && c.last_fractional) maxpo_f = 0;
+	if(fa_frame_fractional(c, w, f)) maxpo_f = 0;
 	else { const uint32_t tz = (uint32_t)__ffs((int)n) - 1u; maxpo_f = tz < c.max_po ? tz : c.max_po; }
 	const uint32_t minpo_f = c.min_po < maxpo_f ? c.min_po : maxpo_f;
 	const uint32_t parts0 = 1u << maxpo_f, dps0 = n >> maxpo_f;
@@ -331,10 +332,14 @@ extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *
 	// full-length frames of common streams go to the register-resident kernel; a short last
 	// frame and everything else to the general one
 	uint32_t fast_frames = 0;
-	if(fa_search_fast_ok(pcm, c)) fast_frames = (c->last_n == c->N) ? c->F : c->F - 1u;
+	FaCfg cc = *c;
+	if(fa_search_fast_ok(pcm, c)) fast_frames = c->multi ? c->F : (c->last_n == c->N) ? c->F : c->F - 1u;
 	fa_launch_search_fast(pcm, c, w, cg, sum64, fast_frames, st);
-	const uint32_t g0 = fast_frames * c->nsig, rest = c->G - g0;
+	// several streams in one batch: short final blocks sit anywhere, both kernels cover all frames and each skips the other's
+	cc.skip_full = (c->multi && fast_frames) ? 1u : 0u;
+	const uint32_t g0 = c->multi ? 0u : fast_frames * c->nsig, rest = c->G - g0;
 	if(rest == 0) return;
+	c = &cc;
 	const size_t lds = fa_search_lds_bytes(c, cg);
 	if(sum64) {
 		(void)hipFuncSetAttribute((const void*)fa_search_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

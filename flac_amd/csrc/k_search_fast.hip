@@ -77,6 +77,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 
 	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
 	const uint32_t n = c.N;
+	if(c.multi && w.frame_len[f] != n) return;   // a stream's short final block: the general kernel codes it
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const uint32_t i0 = tid * SF_CH;

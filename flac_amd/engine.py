@@ -68,6 +68,7 @@ def lib():
         L.flacamd_encoder_max_output_bytes.argtypes = [vp, u32]
         L.flacamd_encoder_max_output_bytes.restype = sz
         L.flacamd_encode_device.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), vp]
+        L.flacamd_encode_streams_device.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp, sz, vp, C.POINTER(u64), vp]
         L.flacamd_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), C.POINTER(u32)]
         L.flacamd_encoder_debug_read.argtypes = [vp, C.c_int, vp, sz]
         L.flacamd_encoder_debug_read.restype = C.c_long
@@ -188,6 +189,16 @@ class Encoder:
         total = C.c_uint64(0)
         _check(self._lib.flacamd_encode_device(self._h, d_pcm_ptr, fmt, nsamples, 1 if final else 0, first_frame, prev_assignment,
                                                 d_out_ptr, out_cap, d_frame_bytes_ptr, C.byref(total), stream), "flacamd_encode_device")
+        return int(total.value)
+
+    def encode_streams_device(self, d_pcm_ptr, fmt, starts, lengths, d_out_ptr, out_cap, d_frame_bytes_ptr, stream=None):
+        """Several complete streams in one pass (flacamd_encode_streams_device): starts / lengths in wide samples,
+        the streams tiling the buffer in whole blocks.  Returns total bytes."""
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        total = C.c_uint64(0)
+        _check(self._lib.flacamd_encode_streams_device(self._h, d_pcm_ptr, fmt, len(st), st.ctypes.data, ln.ctypes.data, d_out_ptr, out_cap,
+                                                        d_frame_bytes_ptr, C.byref(total), stream), "flacamd_encode_streams_device")
         return int(total.value)
 
     def debug(self, what, dtype, count):

@@ -115,6 +115,19 @@ int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
 	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream);
 
+/* Several complete, independent streams of the encoder's format in ONE pass over the device (many short
+ * clips: one call instead of one per clip).  Stream i is h_len[i] wide samples starting at wide sample
+ * h_start[i] of d_pcm; the streams tile the buffer in whole blocks: h_start[0] = 0 and h_start[i + 1] =
+ * h_start[i] + ceil(h_len[i] / blocksize) * blocksize (what lies in the padding is never read as audio).
+ * Every stream is coded as the reference codes a whole stream: frame numbers from 0, loose mid/side
+ * periods from its first frame, a short last block as a final block (stream_encoder.c:1322-1327).  The
+ * frames of all streams come out back to back in stream order, d_frame_bytes gets one size per frame
+ * (stream i owns ceil(h_len[i] / blocksize) consecutive entries).  No counterpart in the reference, which
+ * codes one stream per encoder object. */
+int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nstreams,
+	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint32_t *d_frame_bytes,
+	uint64_t *h_total_bytes, void *stream);
+
 /* Same with host buffers: copies PCM in, frames and sizes out (PCIe inclusive). */
 int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
