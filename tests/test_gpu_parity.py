@@ -1,6 +1,8 @@
 """GPU suite: the HIP engine, called through the C ABI, against the oracle and the golden
 vectors.  Bar: frame bytes bit-exact (integer/byte work; the float stages are kept in the
 reference's evaluation order so their outputs are compared bit-for-bit as well)."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -176,3 +178,52 @@ def test_eight_channel_24bit_exhaustive_precision_search(gpu_engine):
     assert info["frames"] == len(frames) and np.array_equal(back, long_pcm)
     ratio = len(blob) / (long_pcm.size * 3)
     assert 0.3 < ratio < 0.95
+
+
+def _stress_signal(kind, n, rng):
+    t = np.arange(n)
+    if kind == "side-boundary":      # L - R crosses the 16-bit range in some frames only
+        l = (rng.integers(-200, 200, n) + 16384 + 16383 * np.sign(np.sin(t / 9000.0))).clip(-32768, 32767)
+        r = (rng.integers(-200, 200, n) - 16384 * np.sign(np.sin(t / 5000.0)) - (t > n // 2) * 300).clip(-32768, 32767)
+    elif kind == "side-exact":       # side signal exactly -32768 / 32767 / 32768
+        l = np.where((t // 4096) % 3 == 0, -32768, np.where((t // 4096) % 3 == 1, 32767, 32767)) + 0 * t
+        r = np.where((t // 4096) % 3 == 0, 0, np.where((t // 4096) % 3 == 1, 0, -1)) + (t % 7 == 0) * 0
+        l = l + np.where(t % 5 == 0, -1, 0) * (l > 0); r = r + 0
+    elif kind == "loud-noise-tone":  # poor predictors: large predictions, small shifts
+        l = (30000 * np.sin(t * 0.9) + rng.integers(-2700, 2700, n)).astype(np.int64).clip(-32768, 32767)
+        r = (rng.integers(-32768, 32767, n) * (np.sin(t / 3000.0) > 0) + 20000 * np.sin(t * 2.9)).astype(np.int64).clip(-32768, 32767)
+    elif kind == "spikes":           # near silence with rare full-scale spikes: k = 0 partitions beside huge ones
+        l = rng.integers(-1, 2, n) + (rng.random(n) < 0.001) * rng.integers(-32768, 32767, n)
+        r = rng.integers(0, 2, n) + (rng.random(n) < 0.0005) * 32767
+    elif kind == "dc-steps":
+        l = 12345 + 0 * t + (t // 3000) * 257 % 4000
+        r = -30000 + (t // 5000) * 1111 % 9000
+    elif kind == "alternating":      # +-full scale every sample, and a slow one
+        l = np.where(t % 2 == 0, 32767, -32768)
+        r = np.where((t // 37) % 2 == 0, 32767, -32768)
+    elif kind == "wasted-mix":       # different wasted bits per channel and per frame
+        l = (rng.integers(-2000, 2000, n) << np.where((t // 4096) % 2 == 0, 3, 0)).clip(-32768, 32767)
+        r = (rng.integers(-500, 500, n) << 5).clip(-32768, 32767)
+    else:                            # smooth: high orders win, large shifts
+        l = (25000 * np.sin(t * 0.011) + 6000 * np.sin(t * 0.37 + 1)).astype(np.int64)
+        r = (25000 * np.sin(t * 0.0113 + 0.3) - 6000 * np.sin(t * 0.21)).astype(np.int64)
+    return np.stack([np.asarray(l, np.int64), np.asarray(r, np.int64)], axis=1).clip(-32768, 32767).astype(np.int32)
+
+
+@pytest.mark.parametrize("kind", ["side-boundary", "side-exact", "loud-noise-tone", "spikes", "dc-steps", "alternating", "wasted-mix", "smooth"])
+@pytest.mark.parametrize("level,bs", [(8, 4096), (5, 4096), (7, 2048), (3, 1024)])
+def test_stress_signals_on_the_register_resident_path(gpu_engine, kind, level, bs):
+    """Signals aimed at the shortcuts of the stereo 16-bit kernels: the side signal at the edge of 16 bits, predictions far
+    from the samples, near-silent partitions next to loud ones, wasted bits that differ by channel and frame."""
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + level)
+    pcm = _stress_signal(kind, bs * 6 + 100, rng)
+    kw = dict(level=level, blocksize=bs)
+    fp, _ = ob.make_params(2, 16, 44100, **kw)
+    o = ob.oracle_encode(fp, pcm)
+    enc, (frames, _) = _encode(gpu_engine, 2, 16, 44100, kw, pcm)
+    try:
+        assert frames == o["frames"]
+        frames16, _ = enc.encode_host(pcm.astype(np.int16))
+        assert frames16 == o["frames"], "int16 input"
+    finally:
+        enc.close()
