@@ -804,27 +804,31 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 
 __global__ void __launch_bounds__(1024) fa_scan_kernel(FaCfg c, FaWork w)
 {
-	__shared__ unsigned long long wave_tot[16];
-	__shared__ unsigned long long carry;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	if(tid == 0) carry = 0;
-	__syncthreads();
-	for(uint32_t b = 0; b < c.F; b += 1024) {
-		const uint32_t i = b + tid;
-		const unsigned long long v = i < c.F ? w.frame_bytes[i] : 0;
-		unsigned long long inc = v;
+	// Workgroup b owns frames [1024 b, 1024 b + 1024): it sums every frame size ahead of them itself
+	// (coalesced, independent loads that hit L2) and scans its own 1024, so that no workgroup waits for another.
+	__shared__ unsigned long long wave_ahead[16];
+	__shared__ uint32_t wave_own[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, b = blockIdx.x;
+	unsigned long long ahead = 0;
+#pragma unroll 8
+	for(uint32_t i = 0; i < b; i++) ahead += w.frame_bytes[i * 1024u + tid];
+	const uint32_t f = b * 1024u + tid;
+	const uint32_t v = f < c.F ? w.frame_bytes[f] : 0u;
+	uint32_t inc = v; // 64 frames of at most 2^24 bytes each fit 32 bits
 #pragma unroll
-		for(int o = 1; o < 64; o <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
-		if(lane == 63u) wave_tot[wv] = inc;
-		__syncthreads();
-		unsigned long long pre = carry;
-		for(uint32_t k = 0; k < wv; k++) pre += wave_tot[k];
-		if(i < c.F) w.offsets[i] = pre + inc - v;
-		__syncthreads();
-		if(tid == 1023u) carry = pre + inc;
-		__syncthreads();
+	for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
+#pragma unroll
+	for(int o = 32; o >= 1; o >>= 1) ahead += (unsigned long long)__shfl_xor((long long)ahead, o, 64);
+	if(lane == 63u) wave_own[wv] = inc;
+	if(lane == 0u) wave_ahead[wv] = ahead;
+	__syncthreads();
+	unsigned long long base = 0;
+#pragma unroll
+	for(uint32_t k = 0; k < 16u; k++) { base += wave_ahead[k]; if(k < wv) base += wave_own[k]; }
+	if(f < c.F) {
+		w.offsets[f] = base + (inc - v);
+		if(f + 1u == c.F) w.offsets[c.F] = base + inc;
 	}
-	if(tid == 0) w.offsets[c.F] = carry;
 }
 
 // One workgroup per frame: byte-granular destination, 4-byte loads where the source allows
@@ -904,6 +908,6 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 
 extern "C" void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st)
 {
-	hipLaunchKernelGGL(fa_scan_kernel, dim3(1), dim3(1024), 0, st, *c, *w);
+	hipLaunchKernelGGL(fa_scan_kernel, dim3((c->F + 1023u) / 1024u), dim3(1024), 0, st, *c, *w);
 	hipLaunchKernelGGL(fa_gather_kernel, dim3(c->F), dim3(256), 0, st, *c, *w, (uint8_t*)out, (unsigned long long)out_cap, frame_bytes_out);
 }
