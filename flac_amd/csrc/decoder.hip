@@ -32,6 +32,7 @@ struct FdCfg {
 	uint32_t nscan_wg;
 	uint32_t crc_seg_bytes;
 	uint32_t pcm_format;
+	uint32_t tolerant;    // CRC-valid frames that do not follow one another are still written out (the caller sorts out the damage)
 	uint64_t pcm_cap;
 };
 
@@ -40,7 +41,7 @@ struct FdWork {
 	uint32_t *ncand;        // [1]
 	uint64_t *cand_pos;     // [max_frames]
 	uint64_t *cand_end;     // [max_frames] byte just past the frame
-	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bits 4..7 assignment (0..3)
+	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bits 4..7 assignment (0..3), bits 8..11 why parsing stopped
 	uint32_t *cand_bs;      // [max_frames]
 	uint64_t *cand_num;     // [max_frames] frame or sample number from the header
 	int32_t  *ws;           // [max_frames][channels][ws_stride] subframe outputs before decorrelation
@@ -282,22 +283,28 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 	if(!fd_parse_header(bytes, c.nbytes, pos, c, h)) { w.cand_info[ci] = 0; return; }
 	const uint32_t n = h.blocksize;
 	BitReader br; br.init(bytes, c.nbytes, pos + h.hdr_bytes, s_ring, lane);
-	bool ok = true;
+	// Why the walk through the frame stopped, for the caller that replays the reference's error handling on
+	// a damaged stream (the numbers are FLAC__StreamDecoderErrorStatus values where one applies):
+	// 0 none, 1 LOST_SYNC (+1), 4 UNPARSEABLE_STREAM (+1), 5 a field the reference does not define, 6 the frame runs past the buffer
+	uint32_t ex = 0;
+	bool ok = true, undefined = false;
 	for(uint32_t ch = 0; ch < h.channels && ok; ch++) {
 		uint32_t bps = h.bps;
 		if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
 		int32_t *out = w.ws + ((size_t)ci * c.channels + ch) * c.ws_stride;
 		uint32_t head = br.read(8);
-		if(head & 0x80u) { ok = false; break; }                                           // :2481
 		uint32_t wasted = 0;
-		if(head & 1u) { wasted = br.read_unary() + 1u; if(wasted >= bps) { ok = false; break; } bps -= wasted; }
+		if(head & 1u) wasted = br.read_unary() + 1u;                                      // read before the type is looked at (:2468-2476)
+		if(head & 0x80u) { ex = 1; ok = false; break; }                                  // :2481
 		head &= 0xfeu;
+		if(!(head == 0 || head == 2 || (head >= 16 && head <= 24) || head >= 64)) { ex = 4; ok = false; break; }   // reserved subframe types :2494, :2505
+		if(wasted) { if(wasted >= bps) { ex = 5; ok = false; break; } bps -= wasted; }
 		if(head == 0) { const int32_t v = br.read_signed(bps) << wasted; for(uint32_t i = 0; i < n; i++) out[i] = v; }     // constant :2526
 		else if(head == 2) { for(uint32_t i = 0; i < n; i++) { br.top_up(); out[i] = br.read_signed(bps) << wasted; } }                    // verbatim :2698
 		else if((head >= 16 && head <= 24) || head >= 64) {
 			const bool lpc = head >= 64;
 			const uint32_t order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
-			if(order > n || (!lpc && order > 4u)) { ok = false; break; }
+			if(!lpc && order > 4u) { ex = 4; ok = false; break; }                          // :2494-2508 (reserved type codes)
 			// Prediction state.  Orders up to FD_REGORD keep coefficients and history in registers
 			// (unused taps have zero coefficients; a fixed predictor is the order-k predictor with
 			// binomial coefficients and no shift, identical modulo 2^32); larger orders use the
@@ -319,11 +326,13 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			uint32_t prec = 0, shift = 0, wide = 0;
 			if(lpc) {
 				prec = br.read(4);
-				if(prec == 15u) { ok = false; break; }                                   // :2628
+				if(prec == 15u) { ex = 1; ok = false; break; }                           // :2628
 				prec++;
 				const int32_t sh = br.read_signed(5);
-				if(sh < 0) { ok = false; break; }     // never produced by the reference encoder (lpc.c:225-260); shifting by a negative count is undefined there
-				shift = (uint32_t)sh;
+				// a negative shift is never produced by the reference encoder (lpc.c:225-260) and shifting by it is undefined
+				// there; the frame still parses the same way, so go on for the sake of its length
+				if(sh < 0) undefined = true;
+				shift = sh < 0 ? 0u : (uint32_t)sh;
 				for(uint32_t j = 0; j < order; j++) { br.top_up(); s_q[j][lane] = br.read_signed(prec); }
 				// back through the lane's own LDS column with fixed indices (an indexed register array
 				// would be placed in scratch memory)
@@ -338,17 +347,20 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 				else if(order == 4) { qr[0] = 4; qr[1] = -6; qr[2] = 4; qr[3] = -1; }
 			}
 			const uint32_t method = br.read(2);
-			if(method > 1u) { ok = false; break; }                                       // :2580
+			if(method > 1u) { ex = 4; ok = false; break; }                               // :2580
 			const uint32_t po = br.read(4), plen = method ? 5u : 4u, esc = method ? 31u : 15u;
-			if(po == 0) { if(n < order) { ok = false; break; } } else if((n >> po) < order) { ok = false; break; } // :2732-2745
-			if(po > 0 && ((n >> po) << po) != n) { ok = false; break; }
+			if(po == 0) { if(n < order) { ex = 1; ok = false; break; } } else if((n >> po) < order) { ex = 1; ok = false; break; } // :2732-2745
+			// a blocksize that the partition count does not divide: the reference reads (n >> po) samples per partition
+			// all the same (:2727) and leaves the rest of the block undefined
+			const uint32_t nend = po ? ((n >> po) << po) : n;
+			if(nend != n) undefined = true;
 			// One flat loop over the samples of the subframe: the lanes of a wave hold frames with different
 			// partition orders, and nested partition / sample loops would run (most partitions) x (longest
 			// partition) iterations for all of them.  Here every lane advances one sample per iteration and
 			// reads its next partition header when the current partition runs out.
 			uint32_t i = order, left = 0, part = 0, k = 0, raw = 0;
 			bool escaped = false;
-			while(i < n) {
+			while(i < nend) {
 				br.top_up();
 				if(left == 0) {
 					left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
@@ -397,20 +409,23 @@ __global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict
 			if(!ok) break;
 			if(part == 0) { const uint32_t k0 = br.read(plen); if(k0 >= esc) (void)br.read(5); }   // order == blocksize: the one partition is empty, its header is still there
 		}
-		else { ok = false; break; }                                                       // reserved subframe types :2494, :2505
 		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
 	}
 	if(ok) {
 		// zero padding to the byte boundary must be zero (:2779-2795), then the 16-bit CRC
 		const uint32_t pad = (uint32_t)((8u - (br.bitpos & 7u)) & 7u);
-		if(pad && br.read(pad) != 0) ok = false;
-		(void)br.read(16);
-		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
+		if(pad && br.read(pad) != 0) { ex = 1; ok = false; }
+		else {
+			(void)br.read(16);
+			if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
+		}
 	}
-	if(ok) {
-		info = 1u | (h.assignment << 4);
-		w.cand_end[ci] = br.bitpos >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
-	}
+	if(!ok && (ex == 0 || br.err || br.bitpos > c.nbytes * 8u)) ex = 6;
+	(void)undefined;   // such a frame has a length like any other and its CRC-16 decides; were that to hold, the samples are as undefined here as there
+	// cand_end: the byte just past the frame, or where the reference would look for the next sync code
+	// after giving the frame up (frame_sync_ first skips to the byte boundary, :1961-1965)
+	info = (ok ? 1u : 0u) | (h.assignment << 4) | (ex << 8);
+	w.cand_end[ci] = (br.bitpos + 7u) >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
 	w.cand_info[ci] = info;
 }
 
@@ -527,6 +542,7 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 		w.result[3] = nframes ? w.cand_end[w.frame_of[nframes - 1]] : 0;
 		uint32_t err = s_err;
 		if(nframes == 0) err |= 2u;
+		else if(c.tolerant && w.cand_pos[w.frame_of[0]] != 0) err |= 1u;   // bytes ahead of the first frame: the caller reports them
 		if(carry_b > c.pcm_cap) err |= 8u;
 		w.result[4] = err;
 		w.result[5] = nframes ? w.cand_pos[w.frame_of[0]] : 0;
@@ -537,7 +553,7 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 // Undo the inter-channel decorrelation (stream_decoder.c:2073-2108) and write interleaved PCM
 __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, void *__restrict__ pcm)
 {
-	if(w.result[4] != 0) return;
+	if((w.result[4] & (c.tolerant ? ~(uint64_t)3 : ~(uint64_t)0)) != 0) return;
 	const uint32_t r = blockIdx.x;
 	if(r >= (uint32_t)w.result[0]) return;
 	const uint32_t ci = w.frame_of[r];
@@ -579,7 +595,7 @@ struct flacamd_decoder {
 	void *arena; size_t arena_bytes;
 	size_t max_bytes;
 	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
-	uint32_t last_ncand, last_nframes;
+	uint32_t last_ncand, last_nframes, last_damage;
 };
 
 #define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
@@ -658,8 +674,11 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	uint32_t ncand = 0;
 	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
 	FD_TRY(hipStreamSynchronize(st));
-	d->last_ncand = 0; d->last_nframes = 0;
-	if(ncand == 0) return FLACAMD_E_BAD_STREAM;
+	d->last_ncand = 0; d->last_nframes = 0; d->last_damage = 0;
+	if(ncand == 0) {
+		if(c.tolerant) { d->last_damage = 2u; if(h_info) { h_info[0] = h_info[1] = h_info[2] = h_info[3] = 0; } return FLACAMD_OK; }
+		return FLACAMD_E_BAD_STREAM;
+	}
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
 	hipLaunchKernelGGL(fd_decode_kernel, dim3((ncand + 63u) / 64u), dim3(64), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
@@ -671,8 +690,8 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	FD_TRY(hipStreamSynchronize(st));
 	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
 	if(res[4] & 8u) return FLACAMD_E_CAPACITY;
-	if(res[4] != 0) return FLACAMD_E_BAD_STREAM;
-	d->last_ncand = ncand; d->last_nframes = (uint32_t)res[0];
+	if(c.tolerant ? (res[4] & ~(uint64_t)3) != 0 : res[4] != 0) return FLACAMD_E_BAD_STREAM;
+	d->last_ncand = ncand; d->last_nframes = (uint32_t)res[0]; d->last_damage = (uint32_t)(res[4] & 3u);
 	return FLACAMD_OK;
 }
 
@@ -726,4 +745,40 @@ extern "C" int flacamd_decoder_frame_table(flacamd_decoder *d, uint32_t nframes,
 	}
 	free(fo); free(bs); free(info); free(num); free(pos); free(end);
 	return rc;
+}
+
+extern "C" int flacamd_decoder_set_tolerant(flacamd_decoder *d, int on)
+{
+	if(!d) return FLACAMD_E_INVALID_ARGUMENT;
+	d->cfg.tolerant = on ? 1u : 0u;
+	return FLACAMD_OK;
+}
+
+extern "C" uint32_t flacamd_decoder_damage(const flacamd_decoder *d) { return d ? d->last_damage : 0u; }
+
+extern "C" int flacamd_decoder_candidate_table(flacamd_decoder *d, uint32_t max_entries, uint32_t *h_count, uint64_t *h_byte_pos, uint64_t *h_byte_end,
+	uint32_t *h_info, uint32_t *h_blocksize, uint64_t *h_number, uint64_t *h_sample_off)
+{
+	if(!d || !h_count || !h_byte_pos || !h_byte_end || !h_info || !h_blocksize || !h_number || !h_sample_off) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t nc = d->last_ncand, nf = d->last_nframes;
+	*h_count = nc;
+	if(nc > max_entries) return FLACAMD_E_CAPACITY;
+	if(nc == 0) return FLACAMD_OK;
+	FD_TRY(hipSetDevice(d->device));
+	FD_TRY(hipMemcpy(h_byte_pos, d->work.cand_pos, (size_t)nc * 8u, hipMemcpyDeviceToHost));
+	FD_TRY(hipMemcpy(h_byte_end, d->work.cand_end, (size_t)nc * 8u, hipMemcpyDeviceToHost));
+	FD_TRY(hipMemcpy(h_info, d->work.cand_info, (size_t)nc * 4u, hipMemcpyDeviceToHost));
+	FD_TRY(hipMemcpy(h_blocksize, d->work.cand_bs, (size_t)nc * 4u, hipMemcpyDeviceToHost));
+	FD_TRY(hipMemcpy(h_number, d->work.cand_num, (size_t)nc * 8u, hipMemcpyDeviceToHost));
+	for(uint32_t i = 0; i < nc; i++) h_sample_off[i] = ~(uint64_t)0;
+	if(nf) {
+		uint32_t *fo = (uint32_t*)malloc((size_t)nf * 4u); uint64_t *so = (uint64_t*)malloc((size_t)nf * 8u);
+		int rc = FLACAMD_OK;
+		if(!fo || !so) rc = FLACAMD_E_OUT_OF_MEMORY;
+		else if(hipMemcpy(fo, d->work.frame_of, (size_t)nf * 4u, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(so, d->work.sample_off, (size_t)nf * 8u, hipMemcpyDeviceToHost) != hipSuccess) rc = FLACAMD_E_DEVICE;
+		else for(uint32_t r = 0; r < nf; r++) if(fo[r] < nc) h_sample_off[fo[r]] = so[r];
+		free(fo); free(so);
+		if(rc != FLACAMD_OK) return rc;
+	}
+	return FLACAMD_OK;
 }

@@ -44,7 +44,12 @@ struct FLAC__StreamDecoder {
 	/* device decoder and the batch it produced */
 	flacamd_decoder *eng; size_t batch_bytes; unsigned eng_frames;
 	int32_t *pcm; size_t pcm_cap;
-	uint64_t *f_off, *f_num, *f_end; uint32_t *f_bs, *f_asg; unsigned q_n, q_i; FLAC__uint64 batch_base;
+	/* the batch as a queue of events in stream order: frames, and on damaged input also zeroed frames, error
+	 * reports and the end of the stream (f_kind); f_sn is the sample number from the frame header where the
+	 * walk over damaged input took it, else all ones = the running count */
+	uint64_t *f_off, *f_num, *f_end, *f_sn; uint32_t *f_bs, *f_asg; uint8_t *f_kind; unsigned q_n, q_i, ev_cap; FLAC__uint64 batch_base;
+	uint64_t *c_pos, *c_end, *c_num, *c_off; uint32_t *c_info, *c_bs;   /* candidate table of a damaged batch */
+	int search_warned;               /* LOST_SYNC already reported for the sync search in progress (frame_sync_'s `first`) */
 	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
 	int32_t *planar; uint8_t *md5_scratch;
 	md5_state md5;
@@ -74,6 +79,8 @@ static void dec_free(FLAC__StreamDecoder *d)
 	if(d->eng) { flacamd_decoder_destroy(d->eng); d->eng = 0; }
 	free(d->in); d->in = 0; free(d->pcm); d->pcm = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
 	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
+	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
+	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
 }
 
 void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
@@ -315,11 +322,16 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 		if(flacamd_decoder_create(&d->eng, d->device, si->channels, si->bits_per_sample, si->max_blocksize, d->eng_frames, d->batch_bytes) != FLACAMD_OK) {
 			d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0;
 		}
+		(void)flacamd_decoder_set_tolerant(d->eng, 1);
+		d->ev_cap = 4u * d->eng_frames + 64u;
 		d->pcm = (int32_t*)malloc(sizeof(int32_t) * d->pcm_cap * si->channels);
-		d->f_off = (uint64_t*)malloc(8u * d->eng_frames); d->f_num = (uint64_t*)malloc(8u * d->eng_frames); d->f_end = (uint64_t*)malloc(8u * d->eng_frames);
-		d->f_bs = (uint32_t*)malloc(4u * d->eng_frames); d->f_asg = (uint32_t*)malloc(4u * d->eng_frames);
-		d->planar = (int32_t*)malloc(sizeof(int32_t) * (size_t)si->max_blocksize * si->channels);
-		if(!d->pcm || !d->f_off || !d->f_num || !d->f_end || !d->f_bs || !d->f_asg || !d->planar) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		d->f_off = (uint64_t*)malloc(8u * d->ev_cap); d->f_num = (uint64_t*)malloc(8u * d->ev_cap); d->f_end = (uint64_t*)malloc(8u * d->ev_cap); d->f_sn = (uint64_t*)malloc(8u * d->ev_cap);
+		d->f_bs = (uint32_t*)malloc(4u * d->ev_cap); d->f_asg = (uint32_t*)malloc(4u * d->ev_cap); d->f_kind = (uint8_t*)malloc(d->ev_cap);
+		d->c_pos = (uint64_t*)malloc(8u * d->eng_frames); d->c_end = (uint64_t*)malloc(8u * d->eng_frames); d->c_num = (uint64_t*)malloc(8u * d->eng_frames); d->c_off = (uint64_t*)malloc(8u * d->eng_frames);
+		d->c_info = (uint32_t*)malloc(4u * d->eng_frames); d->c_bs = (uint32_t*)malloc(4u * d->eng_frames);
+		d->planar = (int32_t*)calloc((size_t)si->max_blocksize * si->channels, sizeof(int32_t));
+		if(!d->pcm || !d->f_off || !d->f_num || !d->f_end || !d->f_sn || !d->f_bs || !d->f_asg || !d->f_kind || !d->planar
+			|| !d->c_pos || !d->c_end || !d->c_num || !d->c_off || !d->c_info || !d->c_bs) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 	}
 	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
 	return 1;
@@ -377,11 +389,136 @@ static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
 	return 1;
 }
 
+/* ---- damaged input: the reference's serial walk, replayed over what the device found ------------------
+ * The device decodes every position with a plausible frame header at once and says for each how far the
+ * frame parsed and whether its CRC-16 holds.  When those frames do not simply follow one another, the walk
+ * below goes through the bytes the way frame_sync_ / read_frame_ do (stream_decoder.c:1947-2145) and queues
+ * what the client has to see, in order: error reports, frames, and zeroed frames for CRC failures. */
+enum { EV_FRAME = 0, EV_ZERO_FRAME = 1, EV_ERROR = 2, EV_END = 3, EV_END_FAIL = 4, EV_ABORT = 5 };
+
+static void push_event(FLAC__StreamDecoder *d, unsigned kind, unsigned status_or_asg, unsigned bs, uint64_t off, uint64_t sn, uint64_t end)
+{
+	const unsigned r = d->q_n++;
+	d->f_kind[r] = (uint8_t)kind; d->f_asg[r] = status_or_asg; d->f_bs[r] = bs; d->f_off[r] = off; d->f_sn[r] = sn; d->f_end[r] = end; d->f_num[r] = 0;
+}
+
+/* read_frame_header_ (:2147-2454) on the bytes after a sync code at b[s]: 0 = a header the reference accepts,
+ * 1 = BAD_HEADER, 3 = UNPARSEABLE_STREAM (the error status values), -1 = the buffer ends inside the header.
+ * *resume = where the search for the next sync code starts after a rejection. */
+static int probe_header(const FLAC__StreamDecoder *d, const uint8_t *b, size_t n, size_t s, size_t *resume)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	uint8_t raw[16]; unsigned len = 2, i, extra, unparseable = 0, bs_hint = 0, sr_hint = 0, x; size_t p = s + 2; uint8_t crc = 0;
+	const int variable = (b[s + 1] & 1) || si->min_blocksize != si->max_blocksize;
+	raw[0] = b[s]; raw[1] = b[s + 1];
+	for(i = 0; i < 2; i++) { /* :2189-2201: a sync byte inside the header means the sync was false */
+		if(p >= n) return -1;
+		if(b[p] == 0xff) { *resume = p; return 1; }
+		raw[len++] = b[p++];
+	}
+	x = raw[2] >> 4; if(x == 0) unparseable = 1; else if(x == 6 || x == 7) bs_hint = x;
+	x = raw[2] & 15u; if(x == 15) { *resume = p; return 1; } else if(x >= 12) sr_hint = x; /* :2280-2283 */
+	x = raw[3] >> 4; if((x & 8) && (x & 7) > 2) unparseable = 1;
+	x = (raw[3] >> 1) & 7u; if(x == 3 || x == 7) unparseable = 1;
+	if(raw[3] & 1) unparseable = 1;
+	/* the coded number, with the lead-byte tests exactly as bitreader.c:1272-1383 makes them */
+	if(p >= n) return -1;
+	x = b[p]; raw[len++] = b[p++];
+	if(!(x & 0x80)) extra = 0; else if(!(x & 0x20)) extra = 1; else if(!(x & 0x10)) extra = 2; else if(!(x & 0x08)) extra = 3;
+	else if(!(x & 0x04)) extra = 4; else if(!(x & 0x02)) extra = 5; else if(variable && !(x & 0x01)) extra = 6;
+	else { *resume = p - 1; return 1; } /* :2354-2372: the offending byte is looked at again by the sync search */
+	for(i = 0; i < extra; i++) {
+		if(p >= n) return -1;
+		x = b[p]; raw[len++] = b[p++];
+		if(!(x & 0x80) || (x & 0x40)) { *resume = p - 1; return 1; }
+	}
+	if(bs_hint) { if(p >= n) return -1; raw[len++] = b[p++]; if(bs_hint == 7) { if(p >= n) return -1; raw[len++] = b[p++]; } }
+	if(sr_hint) { if(p >= n) return -1; raw[len++] = b[p++]; if(sr_hint != 12) { if(p >= n) return -1; raw[len++] = b[p++]; } }
+	if(p >= n) return -1;
+	for(i = 0; i < len; i++) { unsigned k; crc ^= raw[i]; for(k = 0; k < 8; k++) crc = (uint8_t)((crc & 0x80) ? (crc << 1) ^ 0x07 : crc << 1); }
+	*resume = p + 1;
+	if(crc != b[p]) return 1;      /* :2416-2420 */
+	if(unparseable) return 3;      /* :2447-2451 */
+	return 0;
+}
+
+/* returns bytes consumed; sets d->state only through queued events */
+static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, int at_eof, unsigned ncand)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	const FLAC__uint64 total = si->total_samples;
+	FLAC__uint64 sd = d->samples_decoded;
+	size_t pos = 0; unsigned ci = 0;
+	for(;;) {
+		size_t s, resume = 0; int hr;
+		if(d->q_n + 4u > d->ev_cap) return pos;
+		if(total > 0 && sd >= total) { push_event(d, EV_END, 0, 0, 0, 0, pos); return pos; } /* :1952-1959 */
+		/* frame_sync_ :1967-1997 */
+		for(s = pos; s + 1 < n; s++) if(b[s] == 0xff && (b[s + 1] >> 1) == 0x7c) break;
+		if(s + 1 >= n) {
+			if(at_eof) { /* the read that fails ends the stream; a lone last 0xff is not reported (:1976-1979) */
+				if(!(n == pos || (n - pos == 1 && b[pos] == 0xff)) && !d->search_warned) push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, n);
+				d->search_warned = 0;
+				push_event(d, EV_END, 0, 0, 0, 0, n);
+				return n;
+			}
+			if(n - 1 > pos) {
+				if(!d->search_warned) { push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, n - 1); d->search_warned = 1; }
+				pos = n - 1;
+			}
+			return pos; /* more input needed */
+		}
+		if(s > pos && !d->search_warned) push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, s);
+		d->search_warned = 0;
+		/* read_frame_header_ */
+		hr = probe_header(d, b, n, s, &resume);
+		if(hr < 0) {
+			if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
+			if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+			return s;
+		}
+		if(hr > 0) { push_event(d, EV_ERROR, (unsigned)hr, 0, 0, 0, resume); pos = resume; continue; }
+		while(ci < ncand && d->c_pos[ci] < s) ci++;
+		if(ci >= ncand || d->c_pos[ci] != s) {
+			/* a header the reference would go on to decode with parameters that differ from STREAMINFO's
+			 * (or a blocksize above its maximum): the device decoder is built for the stream's parameters */
+			push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, 0, 0, 0, s);
+			push_event(d, EV_ABORT, 0, 0, 0, 0, s);
+			return s;
+		}
+		{
+			const uint32_t info = d->c_info[ci], ex = (info >> 8) & 15u; const uint64_t end = d->c_end[ci];
+			if(!(info & 1u)) {
+				if(ex == 6u) { /* the frame runs past the buffer */
+					if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
+					if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+					return s;
+				}
+				/* the subframe-level rejections (:2481, :2494-2508, :2580, :2628, :2732-2745, :2785); fields the
+				 * reference does not define end the frame as a lost sync here */
+				push_event(d, EV_ERROR, ex == 4u ? FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM : FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, end);
+				pos = (size_t)end; continue;
+			}
+			{
+				const uint32_t bs = d->c_bs[ci];
+				const int variable = (b[s + 1] & 1) || si->min_blocksize != si->max_blocksize;
+				const uint64_t sn = variable ? d->c_num[ci] : d->c_num[ci] * (uint64_t)si->min_blocksize; /* :2422-2445 */
+				if((info & 2u) && d->c_off[ci] != ~(uint64_t)0) push_event(d, EV_FRAME, (info >> 4) & 15u, bs, d->c_off[ci], sn, end);
+				else { /* :2111-2119 */
+					push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, 0, 0, 0, end);
+					push_event(d, EV_ZERO_FRAME, (info >> 4) & 15u, bs, 0, sn, end);
+				}
+				sd = sn + bs; pos = (size_t)end;
+			}
+		}
+	}
+}
+
 /* decode the next batch of frames on the device; leaves q_n > q_i, or a terminal state */
 static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
-	size_t window; uint64_t info[4] = {0, 0, 0, 0}; int rc;
+	size_t window; uint64_t info[4] = {0, 0, 0, 0}; int rc; unsigned r;
 	d->q_n = d->q_i = 0;
 	if(si->total_samples > 0 && d->samples_decoded >= si->total_samples) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; } /* :1966-1970 */
 	if(!fill(d, d->batch_bytes)) return 0;
@@ -392,44 +529,65 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		if(rc == FLACAMD_E_CAPACITY && window > 1024u) { window /= 2; continue; } /* more frames in the window than a batch holds */
 		break;
 	}
-	if(rc == FLACAMD_E_BAD_STREAM) {
-		/* no frame, or frames that do not follow one another: at the end of the input this is trailing
-		 * junk (the reference ends the same way, :1987-1999); elsewhere a damaged batch */
-		if(info[0] == 0 && d->eof && window == avail(d)) {
-			if(!d->warned_sync) { d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, d->client_data); d->warned_sync = 1; }
-			d->in_pos = d->in_len; d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1;
-		}
-		d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, d->client_data);
-		d->state = FLAC__STREAM_DECODER_ABORTED; return 0;
-	}
 	if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
-	if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, 0, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
-	d->q_n = (unsigned)info[0];
 	d->batch_base = d->in_base + d->in_pos;
-	d->in_pos += (size_t)info[3];
+	if(flacamd_decoder_damage(d->eng) == 0) {
+		const uint8_t *b = d->in + d->in_pos;
+		if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, d->c_pos, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		d->q_n = (unsigned)info[0];
+		for(r = 0; r < d->q_n; r++) { /* the sample number as read_frame_header_ derives it (:2346-2376, :2422-2445) */
+			const int variable = (b[d->c_pos[r] + 1] & 1) || si->min_blocksize != si->max_blocksize;
+			d->f_kind[r] = EV_FRAME; d->f_sn[r] = variable ? d->f_num[r] : d->f_num[r] * (uint64_t)si->min_blocksize;
+		}
+		d->search_warned = 0;
+		d->in_pos += (size_t)info[3];
+	}
+	else {
+		uint32_t ncand = 0; size_t used;
+		if(flacamd_decoder_candidate_table(d->eng, d->eng_frames, &ncand, d->c_pos, d->c_end, d->c_info, d->c_bs, d->c_num, d->c_off) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		used = walk_damaged(d, d->in + d->in_pos, window, d->eof && window == avail(d), ncand);
+		if(d->q_n == 0 && used == 0) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; } /* cannot happen: no progress */
+		d->in_pos += used;
+	}
 	return 1;
 }
 
-/* write_audio_frame_to_client_ (:2915-2990) for the next frame of the batch */
+/* the next frame of the stream: error reports on the way, then write_audio_frame_to_client_ (:2915-2990) */
 static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
-	FLAC__Frame frame; const FLAC__int32 *bufs[8]; unsigned r, c, n, ch = si->channels, skip = 0; const int32_t *src; size_t i;
-	if(d->q_i == d->q_n) {
-		if(!decode_batch(d)) return 0;
-		if(d->q_i == d->q_n) return 1; /* end of stream */
+	FLAC__Frame frame; const FLAC__int32 *bufs[8]; unsigned r, c, n, ch = si->channels, skip = 0, kind; const int32_t *src; size_t i;
+	for(;;) {
+		if(d->q_i == d->q_n) {
+			if(!decode_batch(d)) return 0;
+			if(d->q_i == d->q_n) { if(d->state == FLAC__STREAM_DECODER_END_OF_STREAM || d->state == FLAC__STREAM_DECODER_ABORTED) return 1; continue; }
+		}
+		r = d->q_i++;
+		kind = d->f_kind[r];
+		d->decode_pos = d->batch_base + d->f_end[r];
+		if(kind == EV_ERROR) { d->error_cb(d, (FLAC__StreamDecoderErrorStatus)d->f_asg[r], d->client_data); continue; }
+		if(kind == EV_END) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+		if(kind == EV_END_FAIL) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 0; } /* the input ended inside a frame (:2018, :2054, :2068 return false) */
+		if(kind == EV_ABORT) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		break;
 	}
-	r = d->q_i++;
 	n = d->f_bs[r];
-	src = d->pcm + d->f_off[r] * ch;
-	d->decode_pos = d->batch_base + d->f_end[r];
+	src = kind == EV_FRAME ? d->pcm + d->f_off[r] * ch : 0;
+	if(d->f_sn[r] != ~(uint64_t)0) d->samples_decoded = d->f_sn[r]; /* :2135: the header's number, not a running count */
 	memset(&frame, 0, sizeof frame);
 	frame.header.blocksize = n; frame.header.sample_rate = si->sample_rate; frame.header.channels = ch;
 	frame.header.channel_assignment = (FLAC__ChannelAssignment)d->f_asg[r]; frame.header.bits_per_sample = si->bits_per_sample;
 	frame.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
 	frame.header.number.sample_number = d->samples_decoded; /* frame number x fixed blocksize for the streams this decoder takes (:2422-2445) */
 	d->last = frame.header;
-	if(d->do_md5 && deliver) md5_feed_pcm(&d->md5, src, (size_t)n * ch, si->bits_per_sample, d->md5_scratch, 65536);
+	if(d->do_md5 && deliver) {
+		if(src) md5_feed_pcm(&d->md5, src, (size_t)n * ch, si->bits_per_sample, d->md5_scratch, 65536);
+		else { /* a zeroed frame goes through the checksum like any other (:2964) */
+			size_t left = (size_t)n * ch;
+			memset(d->planar, 0, sizeof(int32_t) * (size_t)si->max_blocksize * ch);
+			while(left) { const size_t k = left < (size_t)si->max_blocksize * ch ? left : (size_t)si->max_blocksize * ch; md5_feed_pcm(&d->md5, d->planar, k, si->bits_per_sample, d->md5_scratch, 65536); left -= k; }
+		}
+	}
 	if(d->is_seeking) { /* :2920-2956: drop frames before the target, trim the one that holds it */
 		const FLAC__uint64 first = d->samples_decoded;
 		if(d->target_sample >= first + n) { d->samples_decoded += n; return 1; }
@@ -441,7 +599,8 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	if(!deliver) return 1;
 	for(c = 0; c < ch; c++) {
 		int32_t *dst = d->planar + (size_t)c * si->max_blocksize;
-		for(i = skip; i < n; i++) dst[i - skip] = src[i * ch + c];
+		if(src) for(i = skip; i < n; i++) dst[i - skip] = src[i * ch + c];
+		else memset(dst, 0, sizeof(int32_t) * n);
 		bufs[c] = dst;
 	}
 	if(d->write_cb(d, &frame, bufs, d->client_data) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }

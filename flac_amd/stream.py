@@ -453,11 +453,11 @@ D_ERROR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 _dec_bound = False
 
 
-def _dec_lib():
-    global _dec_bound
-    L = engine.lib()
-    if not _dec_bound:
-        vp = C.c_void_p
+def bind_decoder_api(L, own=True):
+    """ctypes signatures of the FLAC__stream_decoder_* functions on library L (this library, or any other
+    that exports the same API); own=False leaves out the flacamd_* additions."""
+    vp = C.c_void_p
+    if True:
         L.FLAC__stream_decoder_new.restype = vp
         L.FLAC__stream_decoder_delete.argtypes = [vp]
         L.FLAC__stream_decoder_delete.restype = None
@@ -475,10 +475,19 @@ def _dec_lib():
         L.FLAC__stream_decoder_seek_absolute.argtypes = [vp, C.c_uint64]
         L.FLAC__stream_decoder_init_stream.argtypes = [vp, D_READ_CB, D_SEEK_CB, D_TELL_CB, D_LENGTH_CB, D_EOF_CB, D_WRITE_CB, D_META_CB, D_ERROR_CB, vp]
         L.FLAC__stream_decoder_init_file.argtypes = [vp, C.c_char_p, D_WRITE_CB, D_META_CB, D_ERROR_CB, vp]
-        L.flacamd_stream_decoder_set_device.argtypes = [vp, C.c_int]
-        L.flacamd_stream_decoder_set_batch_frames.argtypes = [vp, C.c_uint]
+        if own:
+            L.flacamd_stream_decoder_set_device.argtypes = [vp, C.c_int]
+            L.flacamd_stream_decoder_set_batch_frames.argtypes = [vp, C.c_uint]
         L.FLAC__stream_decoder_set_metadata_respond_application.argtypes = [vp, C.c_char_p]
         L.FLAC__stream_decoder_set_metadata_ignore_application.argtypes = [vp, C.c_char_p]
+    return L
+
+
+def _dec_lib():
+    global _dec_bound
+    L = engine.lib()
+    if not _dec_bound:
+        bind_decoder_api(L)
         _dec_bound = True
     return L
 
@@ -487,11 +496,12 @@ class StreamDecoder:
     """FLAC::Decoder::Stream (include/FLAC++/decoder.h:97-208) over bytes held in memory (or a file):
     collects what the callbacks deliver.  frames: list of (header dict, int32 array (channels, blocksize))."""
 
-    def __init__(self, data=None, seekable=True, read_chunk=None):
-        self._lib = _dec_lib()
+    def __init__(self, data=None, seekable=True, read_chunk=None, lib=None):
+        self._lib = lib if lib is not None else _dec_lib()   # lib: another library with the same API, already bound
         self._h = C.c_void_p(self._lib.FLAC__stream_decoder_new())
         self.data, self.pos, self.seekable, self.read_chunk = data, 0, seekable, read_chunk
         self.frames, self.errors, self.streaminfo = [], [], None
+        self.events = []     # ("error", status) and ("frame", sample_number, blocksize) in the order the callbacks came
         self.metadata = []   # every non-STREAMINFO block delivered, as plain dicts (see _block_to_dict)
         self._keep = None
 
@@ -544,6 +554,7 @@ class StreamDecoder:
             hdr = dict(blocksize=h.blocksize, sample_rate=h.sample_rate, channels=h.channels, channel_assignment=h.channel_assignment,
                        bits_per_sample=h.bits_per_sample, number_type=h.number_type, sample_number=h.number.sample_number)
             pcm = np.stack([np.ctypeslib.as_array(bufs[c], shape=(h.blocksize,)).copy() for c in range(h.channels)])
+            self.events.append(("frame", int(h.number.sample_number), int(h.blocksize)))
             return int(self.write_callback(hdr, pcm) or 0)
 
         def m(_d, md, _cd):
@@ -557,6 +568,7 @@ class StreamDecoder:
 
         def e(_d, status, _cd):
             self.errors.append(status)
+            self.events.append(("error", int(status)))
 
         return D_WRITE_CB(w), D_META_CB(m), D_ERROR_CB(e)
 

@@ -178,6 +178,28 @@ int flacamd_decode_host(flacamd_decoder *d, const uint8_t *h_bytes, size_t nbyte
 int flacamd_decoder_frame_table(flacamd_decoder *d, uint32_t nframes, uint64_t *h_sample_off, uint32_t *h_blocksize,
 	uint64_t *h_number, uint32_t *h_assignment, uint64_t *h_byte_pos, uint64_t *h_byte_end);
 
+/* Damaged input.  By default a byte range whose CRC-valid frames do not follow one another exactly is
+ * refused (FLACAMD_E_BAD_STREAM).  With tolerant mode on, the decode calls return FLACAMD_OK for such a
+ * range too: every CRC-valid frame is written to the PCM output in order of position, h_info counts
+ * those, and flacamd_decoder_damage() is nonzero (bit 0: frames do not tile the range, bit 1: no frame
+ * at all).  The caller then replays the reference's serial walk (frame_sync_ stream_decoder.c:1947-2000,
+ * read_frame_ :2002-2145) over the candidate table to decide which frames to keep, where zeroed frames
+ * and error callbacks go. */
+int flacamd_decoder_set_tolerant(flacamd_decoder *d, int on);
+uint32_t flacamd_decoder_damage(const flacamd_decoder *d);
+
+/* Every position of the last decode that passed the frame header checks (sync code, legal fields, CRC-8),
+ * in order of position: byte offset, the offset where parsing of the frame stopped (just past its CRC-16
+ * when it parsed completely, else where the reference resumes its search for a sync code), blocksize,
+ * coded frame/sample number, first wide sample in the PCM output (all ones if the frame was not written)
+ * and info: bit 0 parsed to the end, bit 1 CRC-16 correct, bits 4..7 channel assignment, bits 8..11 why
+ * parsing stopped early (1 = the cases the reference reports as LOST_SYNC: stream_decoder.c:2481, :2628,
+ * :2732-2745, :2785; 4 = UNPARSEABLE_STREAM: :2494-2508, :2580, :2659; 5 = a field the reference does not
+ * define; 6 = the frame runs past the end of the buffer).  *h_count receives the number of entries;
+ * FLACAMD_E_CAPACITY if it exceeds max_entries. */
+int flacamd_decoder_candidate_table(flacamd_decoder *d, uint32_t max_entries, uint32_t *h_count, uint64_t *h_byte_pos, uint64_t *h_byte_end,
+	uint32_t *h_info, uint32_t *h_blocksize, uint64_t *h_number, uint64_t *h_sample_off);
+
 /* "fLaC" + STREAMINFO + the empty VORBIS_COMMENT with the reference's vendor string, as the reference
  * leaves them in a finished file (stream_encoder.c:1034-1106 written at init, :2521-2620 patched at
  * finish): for callers that assemble streams from engine output themselves.  Returns the byte count. */

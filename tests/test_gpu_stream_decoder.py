@@ -122,13 +122,17 @@ def test_id3v2_tag_and_trailing_junk(gpu_engine):
 
 
 def test_damaged_frame_is_reported_not_hidden(gpu_engine):
+    # as the reference (stream_decoder.c:2111-2119): an error report, the frame delivered as zeros, decoding goes on
     g = load_golden("st16-level5")
     data = bytearray(_stream_of(g))
     data[42 + len(VC_BLOCK) + len(g["frames"][0]) + 40] ^= 0x10           # inside frame 1
     d = stream.StreamDecoder(bytes(data), seekable=False)
+    assert d.set_md5_checking(True)
     assert d.init() == 0
-    assert not d.process_until_end_of_stream()
-    assert d.errors == [stream.ERR_FRAME_CRC_MISMATCH] and d.get_state() == stream.DEC_ABORTED
+    assert d.process_until_end_of_stream()
+    assert d.errors == [stream.ERR_FRAME_CRC_MISMATCH] and d.get_state() == stream.DEC_END_OF_STREAM
+    assert len(d.frames) == len(g["frames"]) and not d.frames[1][1].any() and d.frames[0][1].any() and d.frames[2][1].any()
+    assert not d.finish()                                                  # the zeros went through the MD5
     d.close()
 
 
