@@ -3,6 +3,7 @@
 // No CPU implementation of any stage lives here: without a HIP device every compute entry
 // point fails with FLACAMD_E_NO_DEVICE.
 #include "engine_types.h"
+#include "residual.h"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -242,6 +243,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		c.slot_bytes = (uint32_t)align_up(16u + p.channels * sub + 2u + 16u, 16u);
 	}
 	{ const char *dbg = getenv("FLACAMD_DEBUG"); c.debug = dbg ? (uint32_t)strtoul(dbg, 0, 0) : 0u; }
+	c.spill = p.blocksize > FA_LDS_BLOCKSIZE ? 1u : 0u;
 	e->cand_group = c.max_cand < 24u ? c.max_cand : 24u;
 	if(e->cand_group == 0) e->cand_group = 1;
 	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
@@ -257,7 +259,8 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u);
+		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
+		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
 	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
@@ -266,6 +269,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.wasted = b + o_wasted; w.is_const = b + o_const; w.fixed_err = (uint64_t*)(b + o_ferr); w.autoc = (float*)(b + o_autoc);
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
+	w.xs_spill = (int32_t*)(b + o_spill);
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)

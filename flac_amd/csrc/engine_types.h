@@ -8,6 +8,7 @@
 #define FA_MAX_QLP_PRECISION 15u
 #define FA_MAX_PARTS (1u << FLACAMD_MAX_PARTITION_ORDER)
 #define FA_DBG_WORDS 131072u
+#define FA_LDS_BLOCKSIZE 16384u   // largest block whose padded 32-bit signal shares LDS with the other per-workgroup tables
 
 // subframe kinds (bitstream order of the type codes)
 enum { FA_SUB_CONSTANT = 0, FA_SUB_VERBATIM = 1, FA_SUB_FIXED = 2, FA_SUB_LPC = 3 };
@@ -29,6 +30,7 @@ struct FaCfg {
 	uint32_t last_fractional; // last frame is the short final block of the stream
 	uint32_t multi;           // the batch holds several complete streams: frame lengths and numbers come from FaWork::frame_len / frame_num
 	uint32_t skip_full;       // general search kernel: full-length frames are left to the register-resident kernel
+	uint32_t spill;           // blocks above FA_LDS_BLOCKSIZE samples: the general kernels keep their copy of the signal in FaWork::xs_spill instead of LDS
 	uint32_t first_frame;     // frame number of frame 0 of the batch
 	uint32_t prev_assignment;
 	uint32_t max_lpc_order, qlp_precision, prec_search, exhaustive;
@@ -116,6 +118,7 @@ struct FaWork {
 	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
 	uint32_t *frame_len;   // [F] samples per frame, multi-stream batches only
 	uint32_t *frame_num;   // [F] frame number within its stream, multi-stream batches only
+	int32_t  *xs_spill;    // [G][xs_words_for(N)] signal copies of the general kernels when FaCfg::spill (else unused)
 	const float *window;   // [num_apod][N]
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial

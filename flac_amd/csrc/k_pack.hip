@@ -238,12 +238,16 @@ __device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bit
 	__syncthreads();
 }
 
+template<bool SPILL>
 __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackShared sh;
-	int32_t *xs = (int32_t*)lds_raw;                            // padded signal, xs_words_for(N) words
-	uint32_t *bitbuf = (uint32_t*)(xs + xs_words_for(c.N));     // [bitbuf_words]
+	// padded signal of the subframe being written, xs_words_for(N) words: in LDS, or for blocks too long for that in the
+	// frame's first row of the spill buffer (this workgroup's alone)
+	int32_t *xs; uint32_t *bitbuf;                              // bitbuf: [bitbuf_words]
+	if constexpr(SPILL) { xs = w.xs_spill + (size_t)blockIdx.x * c.nsig * xs_words_for(c.N); bitbuf = (uint32_t*)lds_raw; }
+	else { xs = (int32_t*)lds_raw; bitbuf = (uint32_t*)(xs + xs_words_for(c.N)); }
 
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
 	const uint32_t n = fa_frame_len(c, w, f);
@@ -389,7 +393,12 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 			}
 			uint32_t round_bits;
 			const uint32_t myoff = block_exscan(mybits, sh, round_bits);
-			if(bitpos + round_bits > cap_bits) { ovf = true; break; }
+			if(bitpos + round_bits > cap_bits) {
+				// long blocks: the buffer holds part of a subframe; write out what is complete and go on behind the carry
+				flush_words(bitbuf, bitpos, slot_words, sh, w, segw, c.debug);
+				bitpos = sh.carry_bits;
+				if(bitpos + round_bits > cap_bits) { ovf = true; break; }
+			}
 			if(mybits && !(c.debug & 0x10u)) {
 				BitRun br; br.begin(bitbuf, bitpos + myoff);
 				if(type <= FA_SUB_VERBATIM) {
@@ -863,9 +872,11 @@ extern "C" size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out)
 	// one subframe never exceeds N * (bps + 2) bits (estimate below verbatim + N/2 slack), plus head and carry
 	const uint32_t maxbps = c->bps + 1u;
 	const size_t bits = (size_t)c->N * (maxbps + 1u) + 8u + 32u + 32u * (maxbps + 15u) + 64u + 64u;
-	const uint32_t words = (uint32_t)((bits + 31u) / 32u) + 4u;
+	uint32_t words = (uint32_t)((bits + 31u) / 32u) + 4u;
+	// long blocks: 128 KB of bit buffer, flushed whenever the next 4096 tokens might not fit
+	if(c->spill && words > 32768u) words = 32768u;
 	if(bitbuf_words_out) *bitbuf_words_out = words;
-	return ((size_t)xs_words_for(c->N) * 4u + (size_t)words * 4u + 15u) & ~(size_t)15u;
+	return ((c->spill ? 0u : (size_t)xs_words_for(c->N) * 4u) + (size_t)words * 4u + 15u) & ~(size_t)15u;
 }
 
 // the fast kernel applies to mono / stereo streams whose blocks fit 256 x 16 samples, whose
@@ -902,8 +913,14 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 	}
 	uint32_t words = 0;
 	const size_t lds = fa_pack_lds_bytes(c, &words);
-	(void)hipFuncSetAttribute((const void*)fa_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(fa_pack_kernel, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);
+	if(c->spill) {
+		(void)hipFuncSetAttribute((const void*)fa_pack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_pack_kernel<true>, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);
+	}
+	else {
+		(void)hipFuncSetAttribute((const void*)fa_pack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(fa_pack_kernel<false>, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);
+	}
 }
 
 extern "C" void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st)

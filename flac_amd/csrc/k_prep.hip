@@ -26,6 +26,8 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
 	return v;
 }
 
+// SPILL: blocks too long for an LDS copy of the signal; the differences re-read the PCM instead (cache hits)
+template<bool SPILL>
 __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w)
 {
 	extern __shared__ int32_t xs[];
@@ -45,7 +47,7 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 	uint32_t acc = 0, ne = 0;
 	for(uint32_t i = tid; i < n; i += 256) {
 		const int32_t v = fa_signal(pcm, c, s, base + i);
-		xs[i] = v;
+		if constexpr(!SPILL) xs[i] = v;
 		acc |= (uint32_t)v;
 		ne |= (v != x0) ? 1u : 0u;
 	}
@@ -59,8 +61,9 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 	// sums of |k-th difference| over samples [4, n), differences wrapping in 32 bits
 	unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
 	for(uint32_t i = tid + FA_MAX_FIXED_ORDER; i < n; i += 256) {
-		const uint32_t a = (uint32_t)(xs[i] >> wasted), b = (uint32_t)(xs[i-1] >> wasted), cc = (uint32_t)(xs[i-2] >> wasted),
-		               d = (uint32_t)(xs[i-3] >> wasted), ee = (uint32_t)(xs[i-4] >> wasted);
+		auto X = [&](uint32_t j) -> int32_t { if constexpr(SPILL) return fa_signal(pcm, c, s, base + j); else return xs[j]; };
+		const uint32_t a = (uint32_t)(X(i) >> wasted), b = (uint32_t)(X(i-1) >> wasted), cc = (uint32_t)(X(i-2) >> wasted),
+		               d = (uint32_t)(X(i-3) >> wasted), ee = (uint32_t)(X(i-4) >> wasted);
 		const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc),
 		              d3 = (int32_t)(a - 3u*b + 3u*cc - d), d4 = (int32_t)(a - 4u*b + 6u*cc - 4u*d + ee);
 		e0 += (uint32_t)(d0 < 0 ? 0u - (uint32_t)d0 : (uint32_t)d0);
@@ -237,6 +240,8 @@ extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w,
 		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
 		return;
 	}
+	if(c->spill) { hipLaunchKernelGGL(fa_prep_kernel<true>, dim3(c->G), dim3(256), 0, st, pcm, *c, *w); return; }
 	const size_t lds = sizeof(int32_t) * (size_t)c->N;
-	hipLaunchKernelGGL(fa_prep_kernel, dim3(c->G), dim3(256), lds, st, pcm, *c, *w);
+	(void)hipFuncSetAttribute((const void*)fa_prep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(fa_prep_kernel<false>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w);
 }

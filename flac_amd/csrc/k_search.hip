@@ -37,7 +37,7 @@ struct SearchShared {
 	uint32_t rice2, group_won;
 };
 
-template<typename SUM>
+template<typename SUM, bool SPILL>
 __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -61,8 +61,11 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	const bool fast = ((n & (CH - 1)) == 0) && ((dps0 & (CH - 1)) == 0);
 
 	// LDS carve-up
-	const uint32_t xs_words = xs_words_for(c.N);
-	int32_t *xs = (int32_t*)lds_raw;
+	// the workgroup's copy of the signal: in LDS, or for blocks too long for that in this signal's row of the spill buffer
+	// (written and read by this workgroup only; the barriers below order it)
+	const uint32_t xs_words = SPILL ? 0u : xs_words_for(c.N);
+	int32_t *xs;
+	if constexpr(SPILL) xs = w.xs_spill + (size_t)g * xs_words_for(c.N); else xs = (int32_t*)lds_raw;
 	// |residual| sums of every partition at every order: row ci holds the finest order first
 	// (parts0 entries), then each coarser order, 2*parts0 - 1 entries in all
 	unsigned long long *psum = (unsigned long long*)(lds_raw + (((size_t)xs_words * 4u + 15u) & ~(size_t)15u)); // [cg][2 * parts_cap]
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 
 extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 {
-	const size_t xs_words = xs_words_for(c->N);
+	const size_t xs_words = c->spill ? 0u : xs_words_for(c->N);
 	const size_t parts_cap = (size_t)1 << (c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER);
 	size_t b = (xs_words * 4u + 15u) & ~(size_t)15u;
 	b += (size_t)cg * 2u * parts_cap * 8u;  // psum, all partition orders
@@ -341,12 +344,10 @@ extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *
 	if(rest == 0) return;
 	c = &cc;
 	const size_t lds = fa_search_lds_bytes(c, cg);
-	if(sum64) {
-		(void)hipFuncSetAttribute((const void*)fa_search_kernel<unsigned long long>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(fa_search_kernel<unsigned long long>, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
-	}
-	else {
-		(void)hipFuncSetAttribute((const void*)fa_search_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(fa_search_kernel<uint32_t>, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
-	}
+	auto launch = [&](auto kernel) {
+		(void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kernel, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
+	};
+	if(c->spill) { if(sum64) launch(fa_search_kernel<unsigned long long, true>); else launch(fa_search_kernel<uint32_t, true>); }
+	else { if(sum64) launch(fa_search_kernel<unsigned long long, false>); else launch(fa_search_kernel<uint32_t, false>); }
 }

@@ -28,7 +28,7 @@ extern "C" {
 #define FLACAMD_MAX_CHANNELS 8
 #define FLACAMD_MAX_LPC_ORDER 32
 #define FLACAMD_MAX_APODIZATIONS 32
-#define FLACAMD_MAX_BLOCKSIZE 16384      /* engine limit (LDS-resident signals) */
+#define FLACAMD_MAX_BLOCKSIZE 65535      /* the format's limit (format.h:108); blocks above 16384 samples take a slower path that keeps the signal in device memory instead of LDS */
 #define FLACAMD_MAX_PARTITION_ORDER 8    /* engine limit; 8 is also the subset limit */
 
 /* error codes */

@@ -28,6 +28,12 @@ def parity_cases(small=False):
         ("st16-8-bs17", lambda: _music(0.1, 26), 2, 16, 44100, dict(level=8, blocksize=17)),
         ("st16-8-bs33", lambda: _music(0.1, 27), 2, 16, 44100, dict(level=8, blocksize=33)),
         ("st16-8-bs16384", lambda: _music(1.5, 28), 2, 16, 44100, dict(level=8, blocksize=16384)),
+        ("st16-8-bs65535", lambda: _music(3.5, 60), 2, 16, 44100, dict(level=8, blocksize=65535)),
+        ("st16-8-bs32768-r8", lambda: _music(2.5, 61), 2, 16, 44100, dict(level=8, blocksize=32768, max_residual_partition_order=8)),
+        ("st24-6-bs20000", lambda: synth.sine(50000, 2, 24, f2=3000.0), 2, 24, 96000, dict(level=6, blocksize=20000)),
+        ("mono16-5-bs40000", lambda: _music(2.0, 62, 1), 1, 16, 44100, dict(level=5, blocksize=40000)),
+        ("white24-bs65535", lambda: synth.white_noise(140000, 2, 24, seed=8), 2, 24, 96000, dict(level=8, blocksize=65535)),
+        ("white16-bs60000", lambda: synth.white_noise(130000, 2, 16, seed=9), 2, 16, 44100, dict(level=5, blocksize=60000)),
         ("st16-8-l32", lambda: _music(s / 2, 29), 2, 16, 44100, dict(level=8, max_lpc_order=32)),
         ("st16-8-l32-p", lambda: _music(0.3, 30), 2, 16, 44100, dict(level=8, max_lpc_order=32, do_qlp_coeff_prec_search=1)),
         ("st16-8-r8", lambda: _music(s / 2, 31), 2, 16, 44100, dict(level=8, max_residual_partition_order=8)),

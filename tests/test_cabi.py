@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_presets_and_resolution_match_oracle():
     olib = ob.oracle_lib()
     for lvl in range(9):
-        for ch, bps, bs in ((2, 16, 0), (1, 16, 1152), (2, 24, 0), (8, 24, 4096), (2, 8, 192), (2, 16, 16384)):
+        for ch, bps, bs in ((2, 16, 0), (1, 16, 1152), (2, 24, 0), (8, 24, 4096), (2, 8, 192), (2, 16, 16384), (2, 16, 32768), (2, 24, 65535)):
             p = engine.make_params(ch, bps, 44100, level=lvl, blocksize=bs)
             assert engine.lib().flacamd_params_resolve(C.byref(p)) == 0
             fp, _ = ob.make_params(ch, bps, 44100, level=lvl, blocksize=bs)
@@ -55,8 +55,6 @@ def test_resolution_rejects_what_the_reference_rejects():
                                **{k: v for k, v in kw.items() if k not in base or k in ("blocksize", "max_lpc_order", "qlp_coeff_precision")})
         assert L.flacamd_params_resolve(C.byref(p)) == -1, kw
     # legal for the reference, outside the engine's limits: reported as such, never silently changed
-    p = engine.make_params(2, 16, 44100, level=8, blocksize=32768)
-    assert L.flacamd_params_resolve(C.byref(p)) == -2
     p = engine.make_params(2, 16, 44100, level=8, max_residual_partition_order=9)
     assert L.flacamd_params_resolve(C.byref(p)) == -2
 

@@ -69,6 +69,8 @@ CASES = {
     "wavext-6ch-24": dict(kind="wav", seconds=1.0, ch=6, bps=24, rate=48000, level=5, tool=["-S-"], kw=dict(seekpoints=""), extensible=True, mask=0x3f),
     "wavext-20in24": dict(kind="wav", seconds=1.0, ch=2, bps=20, rate=48000, level=5, tool=["-T", "WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x9999", "-T", "A=b"],
                           kw=dict(tags=["WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x9999", "A=b"]), extensible=True, mask=0, container=24),
+    "wav16-lax-b65535": dict(kind="wav", seconds=5.0, ch=2, bps=16, rate=44100, level=8, tool=["--lax", "-b", "65535"], kw=dict(lax=True, blocksize=65535)),
+    "wav24-lax-b32768-V": dict(kind="wav", seconds=1.5, ch=2, bps=24, rate=96000, level=5, tool=["--lax", "-b", "32768", "-V"], kw=dict(lax=True, blocksize=32768, verify=True)),
     "aiff16": dict(kind="aiff", seconds=2.5, ch=2, bps=16, rate=44100, level=7, tool=[], kw={}),
     "aiff12-mono-offset": dict(kind="aiff", seconds=1.0, ch=1, bps=12, rate=32000, level=2, tool=["--lax"], kw=dict(lax=True), offset=6),
     "raw16-be": dict(kind="raw", seconds=1.2, ch=2, bps=16, rate=48000, level=4, tool=["--force-raw-format", "--endian=big", "--sign=signed", "--channels=2", "--bps=16", "--sample-rate=48000", "-S", "100", "-S", "40000"],
@@ -107,7 +109,7 @@ def test_encoded_file_equals_the_reference_tools(gpu_engine, tmp_path, name):
     assert r["samples"] == len(pcm) and r["channels"] == c["ch"] and r["bits_per_sample"] == c["bps"] and r["bytes_written"] == want.stat().st_size
 
 
-@pytest.mark.parametrize("name", ["wav16-default", "wav8-mono", "wavext-6ch-24", "wavext-20in24", "aiff12-mono-offset", "wav24-junk-chunks"])
+@pytest.mark.parametrize("name", ["wav16-default", "wav8-mono", "wavext-6ch-24", "wavext-20in24", "aiff12-mono-offset", "wav24-junk-chunks", "wav16-lax-b65535"])
 @pytest.mark.parametrize("fmt", ["wave", "aiff"])
 def test_decoded_file_equals_the_reference_tools(gpu_engine, tmp_path, name, fmt):
     c = CASES[name]

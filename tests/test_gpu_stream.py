@@ -94,6 +94,32 @@ def test_unseekable_stream_matches_live_reference(gpu_engine, seed, level, n, ba
     e.close()
 
 
+@pytest.mark.parametrize("bs,level,bps,n", [(65535, 8, 16, 150000), (32768, 5, 16, 100000), (20000, 6, 24, 50000), (16385, 8, 16, 40000)])
+def test_long_blocks_outside_the_subset(gpu_engine, bs, level, bps, n):
+    """--lax block sizes above 16384 (the format allows 65535): stream equal to the live reference's, verify mode on,
+    and back through the decoder object."""
+    if not ob.have_ref():
+        pytest.skip("oracle/_ref not built")
+    pcm = synth.music_like(n / 44100.0 + 0.01, seed=bs)[:n] if bps == 16 else synth.sine(n, 2, 24, f2=3000.0)
+    rate = 44100 if bps == 16 else 96000
+    _, rp = ob.make_params(2, bps, rate, level=level, blocksize=bs)
+    ref = ob.ref_encode(rp, pcm, chunk=4099)
+    e = stream.MemoryEncoder(seekable=False)
+    _configure(e, 2, bps, rate, dict(level=level, blocksize=bs))
+    assert e.set_verify(1) and e.set_batch_frames(2)
+    assert e.init() == stream.INIT_OK
+    _feed(e, pcm, 30000)
+    assert e.finish()
+    assert bytes(e.buf) == ref["stream"]
+    e.close()
+    d = stream.StreamDecoder(ref["stream"], seekable=False)
+    assert d.set_batch_frames(2) and d.init() == 0
+    assert d.process_until_end_of_stream() and d.errors == []
+    assert np.array_equal(d.pcm(), pcm)
+    assert d.finish()
+    d.close()
+
+
 def test_file_encoder_matches_reference_tool(gpu_engine, tmp_path):
     """init_file + progress callback; byte-for-byte the file the reference's flac tool writes."""
     if not os.path.exists(ob.REF_FLAC):
