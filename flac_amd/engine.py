@@ -84,6 +84,10 @@ def lib():
         L.flacamd_write_stream_head.argtypes = [vp, u32, u32, u32, u32, u32, u32, u64, vp]
         L.flacamd_write_stream_head.restype = sz
         L.flacamd_decoder_frame_table.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+        L.flacamd_decoder_set_tolerant.argtypes = [vp, C.c_int]
+        L.flacamd_decoder_damage.argtypes = [vp]
+        L.flacamd_decoder_damage.restype = u32
+        L.flacamd_decoder_candidate_table.argtypes = [vp, u32, C.POINTER(u32), vp, vp, vp, vp, vp, vp]
         L.flacamd_strerror.argtypes = [C.c_int]
         L.flacamd_strerror.restype = C.c_char_p
         L.flacamd_last_error.restype = C.c_char_p
@@ -242,6 +246,55 @@ class Decoder:
         info = (C.c_uint64 * 4)()
         _check(self._lib.flacamd_decode_host(self._h, buf.ctypes.data, len(buf), pcm.ctypes.data, fmt, cap_samples, info), "flacamd_decode_host")
         return pcm[:int(info[1])], dict(frames=int(info[0]), samples=int(info[1]), first_number=int(info[2]), bytes=int(info[3]))
+
+    def set_tolerant(self, on=True):
+        """Accept byte ranges whose CRC-valid frames do not tile them (flacamd_decoder_set_tolerant)."""
+        _check(self._lib.flacamd_decoder_set_tolerant(self._h, 1 if on else 0), "flacamd_decoder_set_tolerant")
+
+    def damage(self):
+        return int(self._lib.flacamd_decoder_damage(self._h))
+
+    def candidate_table(self, max_entries):
+        """Every plausible frame start of the last decode: dict of arrays pos, end, info, blocksize, number, sample_off."""
+        n = C.c_uint32(0)
+        pos, end, num, off = (np.zeros(max_entries, np.uint64) for _ in range(4))
+        info, bs = (np.zeros(max_entries, np.uint32) for _ in range(2))
+        _check(self._lib.flacamd_decoder_candidate_table(self._h, max_entries, C.byref(n), pos.ctypes.data, end.ctypes.data, info.ctypes.data,
+                                                         bs.ctypes.data, num.ctypes.data, off.ctypes.data), "flacamd_decoder_candidate_table")
+        k = n.value
+        return dict(pos=pos[:k], end=end[:k], info=info[:k], blocksize=bs[:k], number=num[:k], sample_off=off[:k])
+
+    def decode_range(self, data, start, end, slack, cap_samples, max_entries):
+        """The frames of `data` (frames only, no metadata) that START in [start, end): the share of one rank when a
+        stream is cut into byte ranges.  The window decoded is [start, end + slack); slack >= the longest frame, so
+        the last frame of the share is whole.  The first CRC-valid frame at or after `start` opens the chain, every
+        further frame starts where the one before ended.  Returns dict(first_pos, end_pos, frames, pcm): absolute
+        byte offsets of the share, the number of frames and their samples (samples, channels)."""
+        lo, hi = start, min(len(data), end + slack)
+        if lo >= hi:
+            return dict(first_pos=start, end_pos=start, frames=0, pcm=np.zeros((0, self.channels), np.int32))
+        self.set_tolerant(True)
+        pcm, _ = self.decode_host(data[lo:hi], cap_samples)
+        t = self.candidate_table(max_entries)
+        valid = (t["info"] & 3) == 3
+        pos, fin, off, bs = (t[k][valid].astype(np.int64) for k in ("pos", "end", "sample_off", "blocksize"))
+        first = None
+        frames, nxt = 0, None
+        for i in range(len(pos)):
+            if first is None:
+                if pos[i] >= end - lo:
+                    break
+                first, nxt, s0 = i, pos[i], off[i]
+            if pos[i] != nxt:
+                continue            # a position inside an accepted frame that happens to check out: not part of the chain
+            if pos[i] >= end - lo:
+                break
+            frames += 1
+            nxt = fin[i]
+            s1 = off[i] + bs[i]
+        if first is None:
+            return dict(first_pos=min(end, len(data)), end_pos=min(end, len(data)), frames=0, pcm=np.zeros((0, self.channels), np.int32))
+        return dict(first_pos=lo + int(pos[first]), end_pos=lo + int(nxt), frames=frames, pcm=pcm[int(s0):int(s1)].copy())
 
     def decode_device(self, d_bytes_ptr, nbytes, d_pcm_ptr, fmt, cap_samples, stream=None):
         info = (C.c_uint64 * 4)()

@@ -12,6 +12,10 @@ that period: every rank then begins with a period leader and needs no neighbour 
 
 The per-rank encode is injected (`encode_range`): on a GPU box it is
 flac_amd.engine.Encoder.encode_host / encode_device of this rank's GPU.
+
+Decoding shards by byte ranges of the frame data (second half of this file): a rank decodes the frames that
+start in its range, finding the first one by sync code, header CRC-8 and frame CRC-16
+(flac_amd.engine.Decoder.decode_range); rank 0 checks that the shares follow one another and concatenates the PCM.
 """
 import numpy as np
 
@@ -90,3 +94,64 @@ def encode_sharded(encode_range, nsamples, blocksize, align=1, group=None, devic
         return None
     return stitch([g_sizes[r][:counts[r][0]].cpu().numpy() for r in range(world)],
                   [g_bytes[r][:counts[r][1]].cpu().numpy().tobytes() for r in range(world)])
+
+
+# ---- decode: byte ranges --------------------------------------------------------------------------
+
+def byte_ranges(nbytes, world):
+    """Contiguous [first, last) byte ranges of the frame data, one per rank."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    per = -(-nbytes // world)
+    return [(min(r * per, nbytes), min((r + 1) * per, nbytes)) for r in range(world)]
+
+
+def stitch_decoded(parts, nbytes):
+    """parts: per rank, in rank order, dict(first_pos, end_pos, frames, pcm) for the frames that start in the rank's
+    byte range.  A frame carries no length, so a rank finds its first frame by itself (sync code, header CRC-8,
+    frame CRC-16); here the shares are checked to follow one another exactly and to cover [0, nbytes)."""
+    at = 0
+    out = []
+    for r, p in enumerate(parts):
+        if p["frames"] == 0:
+            continue
+        if p["first_pos"] != at:
+            raise ValueError("rank %d starts at byte %d, the stream is decoded up to byte %d" % (r, p["first_pos"], at))
+        at = p["end_pos"]
+        out.append(p["pcm"])
+    if at != nbytes:
+        raise ValueError("frames end at byte %d of %d" % (at, nbytes))
+    ch = parts[0]["pcm"].shape[1] if parts else 0
+    return np.concatenate(out, axis=0) if out else np.zeros((0, ch), np.int32)
+
+
+def decode_sharded(decode_range, nbytes, channels, group=None, device="cpu"):
+    """Decode the frame data of one stream (nbytes bytes, known to every rank) on all ranks of `group`.
+
+    decode_range(first_byte, last_byte) -> dict(first_pos, end_pos, frames, pcm int32 (samples, channels)) for the frames
+    that start in that byte range (flac_amd.engine.Decoder.decode_range on this rank's GPU).  Returns the PCM of the
+    whole stream on rank 0, None elsewhere.  No collective on the data path; the gather of the results runs over
+    RCCL ("nccl", tensors on this rank's GPU) or gloo."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    b0, b1 = byte_ranges(nbytes, world)[rank]
+    part = decode_range(b0, b1)
+    if world == 1:
+        return stitch_decoded([part], nbytes)
+    pcm = np.ascontiguousarray(part["pcm"], dtype=np.int32)
+    mine = torch.tensor([part["first_pos"], part["end_pos"], part["frames"], pcm.shape[0]], dtype=torch.int64, device=device)
+    metas = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(metas, mine, group=group)
+    metas = [[int(v) for v in m] for m in metas]
+    max_s = max(max(m[3] for m in metas), 1)
+    t = torch.zeros((max_s, channels), dtype=torch.int32, device=device)
+    if pcm.shape[0]:
+        t[:pcm.shape[0]] = torch.from_numpy(pcm).to(device)
+    got = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, got, dst=0, group=group)
+    if rank != 0:
+        return None
+    return stitch_decoded([dict(first_pos=m[0], end_pos=m[1], frames=m[2], pcm=got[r][:m[3]].cpu().numpy()) for r, m in enumerate(metas)], nbytes)

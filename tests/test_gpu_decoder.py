@@ -148,3 +148,28 @@ def test_md5_on_device(gpu_engine):
             seg = pcm[int(offs[i]):int(offs[i + 1])].astype("<i4")
             raw = seg.view(np.uint8).reshape(L, ch, 4)[:, :, :nb].tobytes()
             assert got[i] == hashlib.md5(raw).digest(), (ch, bps, i)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("kind", ["music-8", "music-5-bs1152", "mono24"])
+def test_byte_range_shares_stitch_to_the_stream(gpu_engine, world, kind):
+    """Decode sharding: the frame data cut into `world` byte ranges (cuts land inside frames), each share decoded
+    from its own window as a rank would on its GPU, the shares stitched as rank 0 does."""
+    from flac_amd import sharding, synth
+    if kind == "music-8":
+        pcm, ch, bps, fp = synth.music_like(1.6, seed=41)[:65000], 2, 16, ob.make_params(2, 16, 44100, level=8)[0]
+    elif kind == "music-5-bs1152":
+        pcm, ch, bps, fp = synth.music_like(0.8, seed=42)[:30001], 2, 16, ob.make_params(2, 16, 44100, level=5, blocksize=1152)[0]
+    else:
+        pcm, ch, bps, fp = synth.multichannel_24(0.2, channels=1, seed=43)[:15000], 1, 24, ob.make_params(1, 24, 96000, level=6, blocksize=576)[0]
+    enc = ob.oracle_encode(fp, pcm)
+    data = b"".join(enc["frames"])
+    bs = max(enc["samples"])
+    slack = max(len(f) for f in enc["frames"]) + 16
+    dec = gpu_engine.Decoder(ch, bps, bs, max_frames=len(enc["frames"]) + 64, max_bytes=len(data) + 64)
+    parts = [dec.decode_range(data, b0, b1, slack, len(pcm) + bs, len(enc["frames"]) + 64) for b0, b1 in sharding.byte_ranges(len(data), world)]
+    dec.close()
+    assert sum(p["frames"] for p in parts) == len(enc["frames"])
+    assert np.array_equal(sharding.stitch_decoded(parts, len(data)), pcm)
+    if world == 8 and kind == "music-8":
+        assert any(p["frames"] == 0 for p in parts) or all(p["frames"] > 0 for p in parts)   # ranges without a frame start are legal
