@@ -164,5 +164,17 @@ __device__ __forceinline__ int32_t fa_signal(const void *pcm, const FaCfg &c, ui
 // dword index of the record of candidate `slot` of signal g (header at cand_hdr[idx], coefficient j at cand_q[idx + j])
 __device__ __forceinline__ size_t fa_cand_idx(const FaCfg &c, uint32_t g, uint32_t slot) { return ((size_t)g * c.max_cand + slot) * c.cand_stride; }
 
+// Workgroups are handed to the eight XCDs round robin (id mod 8) and each XCD has its own L2.  The signals of one
+// frame are formed from the same PCM bytes, so a launch with one workgroup per (frame, signal) gives the ids
+// b, b + 8, b + 16, ... to the signals of ONE frame: the frame is then fetched from memory once, by one XCD,
+// instead of once per signal.  Returns the signal index g for workgroup b of `total` (a multiple of nsig).
+__device__ __forceinline__ uint32_t fa_xcd_signal(uint32_t b, uint32_t total, uint32_t nsig)
+{
+	const uint32_t span = 8u * nsig, whole = (total / span) * span;
+	if(b >= whole) return b;
+	const uint32_t blk = b / span, r = b - blk * span;
+	return (blk * 8u + (r & 7u)) * nsig + (r >> 3);
+}
+
 __device__ __forceinline__ uint32_t fa_ilog2(uint32_t v) { return 31u - (uint32_t)__clz((int)v); } // v > 0
 #endif

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 	__shared__ uint32_t s_or, s_ne;
 	__shared__ unsigned long long s_err[5];
 
-	const uint32_t g = blockIdx.x, f = g / c.nsig, s = g - f * c.nsig;
+	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig), f = g / c.nsig, s = g - f * c.nsig;   // the signals of a frame share an XCD
 	const uint32_t n = fa_frame_len(c, w, f);
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
 
-	const uint32_t g = blockIdx.x + g0, f = g / c.nsig, s = g - f * c.nsig;   // g0: first signal of the range this launch covers
+	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig) + g0, f = g / c.nsig, s = g - f * c.nsig;   // g0: first signal of the range this launch covers; the signals of a frame share an XCD
 	const uint32_t n = fa_frame_len(c, w, f);
 	if(c.skip_full && n == c.N) return;   // coded by the register-resident kernel
 	const uint64_t base = (uint64_t)f * c.N;

@@ -75,15 +75,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 
-	// Workgroups are handed to the eight XCDs round robin (id mod 8) and each XCD has its own L2.  The signals of
-	// one frame are formed from the same PCM, so ids b, b + 8, b + 16, ... are given to the signals of ONE frame:
-	// the frame is fetched from memory once per XCD that needs it instead of once per signal.
-	uint32_t g = blockIdx.x;
-	{
-		const uint32_t span = 8u * c.nsig, whole = (gridDim.x / span) * span;
-		if(g < whole) { const uint32_t blk = g / span, r = g - blk * span, xcd = r & 7u, sig = r >> 3; g = (blk * 8u + xcd) * c.nsig + sig; }
-	}
-	const uint32_t f = g / c.nsig, s = g - f * c.nsig;
+	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig), f = g / c.nsig, s = g - f * c.nsig;   // the signals of a frame share an XCD
 	const uint32_t n = c.N;
 	if(c.multi && w.frame_len[f] != n) return;   // a stream's short final block: the general kernel codes it
 	const uint64_t base = (uint64_t)f * c.N;
