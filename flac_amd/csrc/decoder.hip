@@ -32,6 +32,7 @@ struct FdCfg {
 	uint32_t nscan_wg;
 	uint32_t crc_seg_bytes;
 	uint32_t pcm_format;
+	uint32_t debug;       // development ablation switches (FLACAMD_DECODE_DEBUG), 0 in production
 	uint32_t tolerant;    // CRC-valid frames that do not follow one another are still written out (the caller sorts out the damage)
 	uint64_t pcm_cap;
 };
@@ -115,10 +116,18 @@ __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict_
 	__shared__ uint32_t s_wave[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint64_t p0 = (uint64_t)blockIdx.x * FD_SCAN_BYTES + (uint64_t)tid * 16u;
+	// the thread's 16 bytes and the one after them in registers (one 16-byte load; the buffer is 16-byte aligned): positions
+	// that hold the two sync bytes are rare, only those go on to the header check
+	uint32_t wd[4] = {0, 0, 0, 0}, nxt = 0;
+	if(p0 + 16u <= c.nbytes) { const uint4 v = *(const uint4*)(b + p0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
+	else for(uint32_t k = 0; k < 16u; k++) if(p0 + k < c.nbytes) wd[k >> 2] |= (uint32_t)b[p0 + k] << (8u * (k & 3u));
+	if(p0 + 16u < c.nbytes) nxt = b[p0 + 16u];
 	uint32_t mask = 0;
+#pragma unroll
 	for(uint32_t k = 0; k < 16; k++) {
-		const uint64_t p = p0 + k;
-		if(p + 1 < c.nbytes && b[p] == 0xffu && (b[p + 1] & 0xfeu) == 0xf8u) { FdHeader h; if(fd_parse_header(b, c.nbytes, p, c, h)) mask |= 1u << k; }
+		const uint32_t b0 = (wd[k >> 2] >> (8u * (k & 3u))) & 0xffu;
+		const uint32_t b1 = k < 15u ? (wd[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xffu : nxt;
+		if(b0 == 0xffu && (b1 & 0xfeu) == 0xf8u && p0 + k + 1u < c.nbytes) { FdHeader h; if(fd_parse_header(b, c.nbytes, p0 + k, c, h)) mask |= 1u << k; }
 	}
 	const uint32_t cnt = (uint32_t)__popc(mask);
 	// in-workgroup exclusive scan of the per-thread counts
@@ -165,75 +174,90 @@ __global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w
 
 #define FD_RING_WORDS 64u   // per-lane window of the stream kept in LDS, in 32-bit words
 #define FD_LOW_WORDS 24u    // top up when any lane of the wave has fewer words than this ahead of it
+// The last, partial 16 bytes of the buffer, byte by byte and never past the end.  Out of line on purpose: the bit reader
+// is inlined at every place a field is read, and this rarely taken path would otherwise be copied into all of them
+// (the decode kernel then no longer fits the instruction cache).
+__device__ __noinline__ uint4 fd_load_chunk_tail(const uint8_t *b, uint64_t nbytes, uint64_t off)
+{
+	uint32_t v[4] = {0, 0, 0, 0};
+	for(uint32_t k = 0; k < 16u; k++) if(off + k < nbytes) v[k >> 2] |= (uint32_t)b[off + k] << (8u * (k & 3u));
+	return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// 16 more bytes of the stream into a lane's column of the ring, for a reader that ran dry between two top-ups.  Out of
+// line for the same reason as fd_load_chunk_tail.
+__device__ __noinline__ void fd_ring_fetch(uint32_t (*ring)[64], uint32_t lane, const uint8_t *b, uint64_t nbytes, uint32_t wr)
+{
+	const uint64_t off = (uint64_t)(wr >> 2) * 16u;
+	const uint4 v = (off + 16u <= nbytes) ? *(const uint4*)(b + off) : fd_load_chunk_tail(b, nbytes, off);
+	const uint32_t r = wr & (FD_RING_WORDS - 1u);
+	ring[r][lane] = v.x; ring[r + 1u][lane] = v.y; ring[r + 2u][lane] = v.z; ring[r + 3u][lane] = v.w;
+}
+
 struct BitReader {
 	// The stream is consumed through a 64-bit register window refilled 32 bits at a time from a per-lane
 	// ring of words in LDS (column `lane` of ring[][64]).  The ring is topped up by top_up(), which the
 	// decode loop calls at a point all lanes of the wave pass together: memory latency is then paid once
 	// per 64 bytes for the whole wave.  (Fetching on demand inside the token readers made every lane's
 	// fetch a wait for all lanes: a wave-wide wait for the newest load on nearly every iteration.)
-	const uint8_t *b; uint64_t nbytes, widx, wr, bitpos; unsigned long long buf; uint32_t avail; bool err;
+	// buf holds `avail` unread bits from its top; widx is the index of the next stream word to go into buf, and that word
+	// is already on its way from the ring (nextw): its LDS latency stays off the token-to-token dependency chain
+	// (word indices in 32 bits: a buffer of up to 16 GB)
+	const uint8_t *b; uint64_t nbytes; uint32_t widx, wr; unsigned long long buf; uint32_t avail, nextw; bool err;
+	__device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)widx * 32u - avail; }
 	uint32_t (*ring)[64]; uint32_t lane;
-	__device__ __forceinline__ uint4 load_chunk(uint64_t ck) const
+	__device__ __forceinline__ uint4 load_chunk(uint32_t ck) const
 	{
-		const uint64_t off = ck * 16u;
+		const uint64_t off = (uint64_t)ck * 16u;
 		if(off + 16u <= nbytes) return *(const uint4*)(b + off);
-		uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;   // tail of the buffer: byte by byte, never past the end
-		if(off < nbytes) {
-#pragma unroll
-			for(uint32_t k = 0; k < 4u; k++) {
-				if(off + k < nbytes) v0 |= (uint32_t)b[off + k] << (8u * k);
-				if(off + 4u + k < nbytes) v1 |= (uint32_t)b[off + 4u + k] << (8u * k);
-				if(off + 8u + k < nbytes) v2 |= (uint32_t)b[off + 8u + k] << (8u * k);
-				if(off + 12u + k < nbytes) v3 |= (uint32_t)b[off + 12u + k] << (8u * k);
-			}
-		}
-		return make_uint4(v0, v1, v2, v3);
+		return fd_load_chunk_tail(b, nbytes, off);
 	}
-	__device__ __forceinline__ void store_chunk(uint64_t at, const uint4 &v)
+	__device__ __forceinline__ void store_chunk(uint32_t at, const uint4 &v)
 	{
-		const uint32_t r = (uint32_t)at & (FD_RING_WORDS - 1u);   // `at` is a multiple of 4
+		const uint32_t r = at & (FD_RING_WORDS - 1u);   // `at` is a multiple of 4
 		ring[r][lane] = v.x; ring[r + 1u][lane] = v.y; ring[r + 2u][lane] = v.z; ring[r + 3u][lane] = v.w;
 	}
 	// wave-uniform call site: 64 more bytes for every lane that has room, when any lane runs low
 	__device__ __forceinline__ void top_up()
 	{
-		const uint32_t ahead = (uint32_t)(wr - widx);
+		const uint32_t ahead = wr - widx;
 		if(__any(ahead < FD_LOW_WORDS ? 1 : 0)) {
 			if(ahead + 16u <= FD_RING_WORDS) {
-				const uint64_t ck = wr >> 2;
+				const uint32_t ck = wr >> 2;
 				const uint4 v0 = load_chunk(ck), v1 = load_chunk(ck + 1u), v2 = load_chunk(ck + 2u), v3 = load_chunk(ck + 3u);
 				store_chunk(wr, v0); store_chunk(wr + 4u, v1); store_chunk(wr + 8u, v2); store_chunk(wr + 12u, v3);
 				wr += 16u;
 			}
 		}
 	}
-	__device__ __forceinline__ uint32_t load_word(uint64_t wi)
+	__device__ __forceinline__ uint32_t load_word(uint32_t wi)
 	{
-		if(wi >= wr) { store_chunk(wr, load_chunk(wr >> 2)); wr += 4u; }   // ran dry between two top-ups (a very long token): fetch alone
-		return __builtin_bswap32(ring[(uint32_t)wi & (FD_RING_WORDS - 1u)][lane]);
+		if(wi >= wr) { fd_ring_fetch(ring, lane, b, nbytes, wr); wr += 4u; }   // ran dry between two top-ups (a very long token): fetch alone, out of line
+		return __builtin_bswap32(ring[wi & (FD_RING_WORDS - 1u)][lane]);
 	}
-	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)load_word(widx++) << (32u - avail); avail += 32u; } }
+	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)nextw << (32u - avail); avail += 32u; widx++; nextw = load_word(widx); } }
 	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos, uint32_t (*ring_)[64], uint32_t lane_)
 	{
-		b = base; nbytes = nb; widx = pos >> 2; buf = 0; avail = 0; err = false; bitpos = (pos >> 2) * 32u;
+		b = base; nbytes = nb; widx = (uint32_t)(pos >> 2); buf = 0; avail = 0; err = false;
 		ring = ring_; lane = lane_;
-		wr = widx & ~(uint64_t)3;
+		wr = widx & ~3u;
 		{
-			const uint64_t ck = wr >> 2;
+			const uint32_t ck = wr >> 2;
 			const uint4 v0 = load_chunk(ck), v1 = load_chunk(ck + 1u), v2 = load_chunk(ck + 2u), v3 = load_chunk(ck + 3u);
 			store_chunk(wr, v0); store_chunk(wr + 4u, v1); store_chunk(wr + 8u, v2); store_chunk(wr + 12u, v3);
 			wr += 16u;
 		}
+		nextw = load_word(widx);
 		refill();
 		const uint32_t skip = (uint32_t)(pos & 3u) * 8u;
-		buf <<= skip; avail -= skip; bitpos += skip;
+		buf <<= skip; avail -= skip;
 	}
 	// n in 1..32
 	__device__ __forceinline__ uint32_t read(uint32_t n)
 	{
 		refill();
 		const uint32_t v = (uint32_t)(buf >> (64u - n));
-		buf <<= n; avail -= n; bitpos += n;
+		buf <<= n; avail -= n;
 		return v;
 	}
 	__device__ __forceinline__ int32_t read_signed(uint32_t n)
@@ -249,184 +273,302 @@ struct BitReader {
 		for(;;) {
 			refill();
 			if(buf == 0) {
-				q += avail; bitpos += avail; avail = 0;
-				if(bitpos > nbytes * 8u + 64u || q > (1u << 26)) { err = true; return 0; }
+				q += avail; avail = 0;
+				if(bitpos() > nbytes * 8u + 64u || q > (1u << 26)) { err = true; return 0; }
 				continue;
 			}
 			const uint32_t lz = (uint32_t)__clzll((long long)buf);
 			q += lz;
 			buf <<= (lz + 1u) & 63u; if(lz == 63u) buf = 0;
-			avail -= lz + 1u; bitpos += lz + 1u;
+			avail -= lz + 1u;
 			return q;
 		}
+	}
+	// one Rice token with parameter k < 32: q zero bits, a one, k bits; returns (q << k) | bits.  When the whole token lies in
+	// the upper word of the window (nearly always) it costs one count-leading-zeros, two shifts and one shift of the window.
+	__device__ __forceinline__ uint32_t read_rice(uint32_t k)
+	{
+		refill();
+		const uint32_t hi = (uint32_t)(buf >> 32);
+		const uint32_t lz = hi ? (uint32_t)__clz((int)hi) : 32u;
+		if(lz + k <= 31u) {
+			const uint32_t low = ((hi << lz) >> (31u - k)) & ((1u << k) - 1u);
+			const uint32_t len = lz + 1u + k;
+			buf <<= len; avail -= len;
+			return (lz << k) | low;
+		}
+		const uint32_t qv = read_unary();
+		const uint32_t low = k ? read(k) : 0u;
+		return (qv << k) | low;
 	}
 };
 
 #define FD_RING 32u
 #define FD_REGORD 12
 
-__global__ void __launch_bounds__(64) fd_decode_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
+// ---- speculative decode: a two-wave pipeline per 64 candidates ---------------------------------------
+//
+// One lane per candidate alone leaves most of the chip idle (an hour of stereo is 38 760 frames: 606 waves for
+// 1024 SIMDs) and each lane walks one long dependent chain.  The chain has two halves that only meet in one
+// direction: parsing the bit stream (where a token ends depends on the token before it) and restoring the
+// signal from the residuals (a sample depends on the samples before it); the parser never needs a restored
+// sample.  So a workgroup is two waves over the same 64 candidates: wave 0 parses and hands what it finds
+// (subframe descriptions, warm-up samples, residuals) to wave 1 through a pair of LDS buffers, wave 1 restores
+// and stores while wave 0 parses on.  The buffers change hands at barriers that both waves reach the same
+// number of times by construction (the parser's loop structure is wave-uniform; what differs per lane is
+// predicated), so nothing ever spins or waits on a flag.
+#define FD_K 32u      // parser steps between two hand-overs (one item per step at most)
+#define FD_CAP 38u    // items per lane and buffer: a subframe head is at most 1 + 1 + 32 + 1 + 1 items
+struct FdPipe {
+	int32_t buf[2][FD_CAP][64];
+	uint32_t cnt[2][64];
+	uint32_t more[2];
+};
+
+__global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
-	// per-lane predictor coefficients and sample history, column `lane` of [32][64] arrays:
-	// any mix of per-lane row indices stays bank-conflict free
-	__shared__ int32_t s_q[FD_RING][64];
-	__shared__ int32_t s_h[FD_RING][64];
+	__shared__ FdPipe pipe;
+	__shared__ int16_t s_q[FD_RING][64];    // coefficients of the subframe whose head the parser read last (parser -> restorer)
+	__shared__ int16_t s_qb[FD_RING][64];   // the restorer's copy, for orders above FD_REGORD
+	__shared__ int32_t s_h[FD_RING][64];    // the restorer's sample history, for orders above FD_REGORD
 	__shared__ uint32_t s_ring[FD_RING_WORDS][64];
-	const uint32_t lane = threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, role = threadIdx.x >> 6;
 	const uint32_t ci = blockIdx.x * 64u + lane;
 	const uint32_t ncand = w.ncand[0] < c.max_frames ? w.ncand[0] : c.max_frames;
-	if(ci >= ncand) return;
-	const uint64_t pos = w.cand_pos[ci];
-	FdHeader h;
-	uint32_t info = 0;
-	w.cand_end[ci] = pos; w.cand_bs[ci] = 0; w.cand_num[ci] = 0;
-	if(!fd_parse_header(bytes, c.nbytes, pos, c, h)) { w.cand_info[ci] = 0; return; }
-	const uint32_t n = h.blocksize;
-	BitReader br; br.init(bytes, c.nbytes, pos + h.hdr_bytes, s_ring, lane);
-	// Why the walk through the frame stopped, for the caller that replays the reference's error handling on
-	// a damaged stream (the numbers are FLAC__StreamDecoderErrorStatus values where one applies):
-	// 0 none, 1 LOST_SYNC (+1), 4 UNPARSEABLE_STREAM (+1), 5 a field the reference does not define, 6 the frame runs past the buffer
-	uint32_t ex = 0;
-	bool ok = true, undefined = false;
-	for(uint32_t ch = 0; ch < h.channels && ok; ch++) {
-		uint32_t bps = h.bps;
-		if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
-		int32_t *out = w.ws + ((size_t)ci * c.channels + ch) * c.ws_stride;
-		uint32_t head = br.read(8);
-		uint32_t wasted = 0;
-		if(head & 1u) wasted = br.read_unary() + 1u;                                      // read before the type is looked at (:2468-2476)
-		if(head & 0x80u) { ex = 1; ok = false; break; }                                  // :2481
-		head &= 0xfeu;
-		if(!(head == 0 || head == 2 || (head >= 16 && head <= 24) || head >= 64)) { ex = 4; ok = false; break; }   // reserved subframe types :2494, :2505
-		if(wasted) { if(wasted >= bps) { ex = 5; ok = false; break; } bps -= wasted; }
-		if(head == 0) { const int32_t v = br.read_signed(bps) << wasted; for(uint32_t i = 0; i < n; i++) out[i] = v; }     // constant :2526
-		else if(head == 2) { for(uint32_t i = 0; i < n; i++) { br.top_up(); out[i] = br.read_signed(bps) << wasted; } }                    // verbatim :2698
-		else if((head >= 16 && head <= 24) || head >= 64) {
-			const bool lpc = head >= 64;
-			const uint32_t order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
-			if(!lpc && order > 4u) { ex = 4; ok = false; break; }                          // :2494-2508 (reserved type codes)
-			// Prediction state.  Orders up to FD_REGORD keep coefficients and history in registers
-			// (unused taps have zero coefficients; a fixed predictor is the order-k predictor with
-			// binomial coefficients and no shift, identical modulo 2^32); larger orders use the
-			// per-lane LDS columns.
-			int32_t qr[FD_REGORD], hr[FD_REGORD];
-#pragma unroll
-			for(int j = 0; j < FD_REGORD; j++) { qr[j] = 0; hr[j] = 0; }
-			const bool in_regs = order <= (uint32_t)FD_REGORD;
-			uint32_t hp = 0;
-			for(uint32_t i = 0; i < order; i++) {
-				br.top_up();
-				const int32_t v = br.read_signed(bps);
-				out[i] = v << wasted;
-				s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
-#pragma unroll
-				for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
-				hr[0] = v;
-			}
-			uint32_t prec = 0, shift = 0, wide = 0;
-			if(lpc) {
-				prec = br.read(4);
-				if(prec == 15u) { ex = 1; ok = false; break; }                           // :2628
-				prec++;
-				const int32_t sh = br.read_signed(5);
-				// a negative shift is never produced by the reference encoder (lpc.c:225-260) and shifting by it is undefined
-				// there; the frame still parses the same way, so go on for the sake of its length
-				if(sh < 0) undefined = true;
-				shift = sh < 0 ? 0u : (uint32_t)sh;
-				for(uint32_t j = 0; j < order; j++) { br.top_up(); s_q[j][lane] = br.read_signed(prec); }
-				// back through the lane's own LDS column with fixed indices (an indexed register array
-				// would be placed in scratch memory)
-#pragma unroll
-				for(int t = 0; t < FD_REGORD; t++) qr[t] = ((uint32_t)t < order) ? s_q[t][lane] : 0;
-				wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
-			}
-			else { // fixed.c:395-435
-				if(order == 1) { qr[0] = 1; }
-				else if(order == 2) { qr[0] = 2; qr[1] = -1; }
-				else if(order == 3) { qr[0] = 3; qr[1] = -3; qr[2] = 1; }
-				else if(order == 4) { qr[0] = 4; qr[1] = -6; qr[2] = 4; qr[3] = -1; }
-			}
-			const uint32_t method = br.read(2);
-			if(method > 1u) { ex = 4; ok = false; break; }                               // :2580
-			const uint32_t po = br.read(4), plen = method ? 5u : 4u, esc = method ? 31u : 15u;
-			if(po == 0) { if(n < order) { ex = 1; ok = false; break; } } else if((n >> po) < order) { ex = 1; ok = false; break; } // :2732-2745
-			// a blocksize that the partition count does not divide: the reference reads (n >> po) samples per partition
-			// all the same (:2727) and leaves the rest of the block undefined
-			const uint32_t nend = po ? ((n >> po) << po) : n;
-			if(nend != n) undefined = true;
-			// One flat loop over the samples of the subframe: the lanes of a wave hold frames with different
-			// partition orders, and nested partition / sample loops would run (most partitions) x (longest
-			// partition) iterations for all of them.  Here every lane advances one sample per iteration and
-			// reads its next partition header when the current partition runs out.
-			uint32_t i = order, left = 0, part = 0, k = 0, raw = 0;
-			bool escaped = false;
-			while(i < nend) {
-				br.top_up();
-				if(left == 0) {
-					left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
-					part++;
-					k = br.read(plen);
-					escaped = k >= esc;
-					if(escaped) raw = br.read(5);
-					if(br.err) { ok = false; break; }
-					if(left == 0) continue;   // first partition as long as the predictor order: no residual in it
+	const bool live = ci < ncand;
+
+	if(role == 0) {
+		// ================= parser =================
+		uint32_t pb = 0, np = 0;
+		auto push = [&](int32_t v) { if(np < FD_CAP) pipe.buf[pb][np][lane] = v; np++; };
+		auto hand_over = [&](bool last) {
+			pipe.cnt[pb][lane] = np < FD_CAP ? np : FD_CAP;
+			if(lane == 0) pipe.more[pb] = last ? 0u : 1u;
+			__syncthreads();
+			pb ^= 1u; np = 0;
+		};
+		FdHeader h; h.blocksize = 0; h.assignment = 0; h.channels = c.channels; h.bps = c.bps; h.hdr_bytes = 0; h.number = 0;
+		uint64_t pos = 0;
+		bool ok = live;
+		if(live) {
+			pos = w.cand_pos[ci];
+			w.cand_end[ci] = pos; w.cand_bs[ci] = 0; w.cand_num[ci] = 0;
+			if(!fd_parse_header(bytes, c.nbytes, pos, c, h)) { w.cand_info[ci] = 0; ok = false; }
+		}
+		const bool parsed_header = ok;
+		const uint32_t n = h.blocksize;
+		BitReader br; br.init(bytes, c.nbytes, ok ? pos + h.hdr_bytes : 0, s_ring, lane);
+		uint32_t ex = 0;
+		if(ok) push((int32_t)n);
+		for(uint32_t ch = 0; ch < c.channels; ch++) {
+			// ---- head of the subframe (per lane, no barrier inside)
+			uint32_t bps = h.bps, wasted = 0, order = 0, type = 0, nres = 0, po = 0, plen = 4, esc = 15;
+			if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
+			if(ok) do {
+				uint32_t head = br.read(8);
+				if(head & 1u) wasted = br.read_unary() + 1u;                                      // read before the type is looked at (:2468-2476)
+				if(head & 0x80u) { ex = 1; ok = false; break; }                                  // :2481
+				head &= 0xfeu;
+				if(!(head == 0 || head == 2 || (head >= 16 && head <= 24) || head >= 64)) { ex = 4; ok = false; break; }   // reserved subframe types :2494, :2505
+				if(wasted) { if(wasted >= bps) { ex = 5; ok = false; break; } bps -= wasted; }
+				if(head == 0) { type = 0; push((int32_t)(0u | (wasted << 8))); push(1); push(br.read_signed(bps)); break; }   // constant :2526
+				if(head == 2) { type = 1; nres = n; push((int32_t)(1u | (wasted << 8))); push((int32_t)n); break; }            // verbatim :2698
+				const bool lpc = head >= 64;
+				type = lpc ? 3u : 2u;
+				order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
+				if(!lpc && order > 4u) { ex = 4; ok = false; break; }                          // :2494-2508 (reserved type codes)
+				push((int32_t)(type | (order << 2) | (wasted << 8)));
+				for(uint32_t i = 0; i < order; i++) { br.top_up(); push(br.read_signed(bps)); }
+				uint32_t shift = 0, wide = 0;
+				if(lpc) {
+					uint32_t prec = br.read(4);
+					if(prec == 15u) { ex = 1; ok = false; break; }                           // :2628
+					prec++;
+					const int32_t sh = br.read_signed(5);
+					// a negative shift is never produced by the reference encoder (lpc.c:225-260) and shifting by it is undefined
+					// there; the frame still parses the same way, so go on for the sake of its length
+					shift = sh < 0 ? 0u : (uint32_t)sh;
+					for(uint32_t j = 0; j < order; j++) { br.top_up(); s_q[j][lane] = (int16_t)br.read_signed(prec); }
+					wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
 				}
-				int32_t r;
-				if(!escaped) {
-					const uint32_t qv = br.read_unary();
-					const uint32_t low = k ? br.read(k) : 0u;
-					const uint32_t u = (qv << k) | low;
-					r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-				}
-				else r = br.read_signed(raw);
-				int32_t x;
-				if(in_regs) {
-					if(wide) {
-						long long sum = 0;
-#pragma unroll
-						for(int j = 0; j < FD_REGORD; j++) sum += (long long)qr[j] * (long long)hr[j];
-						x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift));
+				const uint32_t method = br.read(2);
+				if(method > 1u) { ex = 4; ok = false; break; }                               // :2580
+				po = br.read(4); plen = method ? 5u : 4u; esc = method ? 31u : 15u;
+				if(po == 0) { if(n < order) { ex = 1; ok = false; break; } } else if((n >> po) < order) { ex = 1; ok = false; break; } // :2732-2745
+				// a blocksize that the partition count does not divide: the reference reads (n >> po) samples per partition
+				// all the same (:2727) and leaves the rest of the block undefined
+				const uint32_t nend = po ? ((n >> po) << po) : n;
+				nres = nend - order;
+				push((int32_t)(nres | (shift << 16) | (wide << 21)));
+				if(br.err) ok = false;
+			} while(0);
+			hand_over(false);
+			// ---- one value per step for every lane that still has some (residuals, or the samples of a verbatim subframe);
+			// partition headers are read where a partition runs out
+			// Every step refills the window once (at least 33 bits) and then takes at most 32 bits from it, whatever it is
+			// reading: a partition header, a whole Rice token (nearly always), or a piece of a long one - the zeros of a long
+			// unary run 32 at a time, the low bits on their own when they did not fit.  One refill site and no nested reader
+			// calls keep the loop small enough to stay in the instruction cache.
+			enum { M_HDR = 0, M_TOKEN = 1, M_LOW = 2, M_RAWHDR = 3, M_RAW = 4, M_VERB = 5 };
+			uint32_t left = 0, part = 0, k = 0, raw = 0, qacc = 0, todo = (ok && type != 0u) ? nres : 0u;
+			uint32_t mode = type == 1u ? (uint32_t)M_VERB : (uint32_t)M_HDR;
+			for(uint32_t it = 0; __any(todo != 0u ? 1 : 0); it++) {
+				if((it & 3u) == 0u && !(c.debug & 4u)) br.top_up();   // four steps take at most four words
+				if(todo != 0u) {
+					br.refill();
+					const uint32_t hi = (uint32_t)(br.buf >> 32);
+					uint32_t take = 0; int32_t r = 0; bool have = false;
+					if(mode == M_TOKEN) {
+						const uint32_t lz = hi ? (uint32_t)__clz((int)hi) : 32u;
+						if(lz + k <= 31u) {
+							const uint32_t low = ((hi << lz) >> (31u - k)) & ((1u << k) - 1u);
+							const uint32_t u = ((qacc + lz) << k) | low;
+							r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+							take = lz + 1u + k; qacc = 0; have = true;
+						}
+						else if(lz == 32u) {
+							qacc += 32u; take = 32u;
+							if(qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u) { br.err = true; }
+						}
+						else { qacc += lz; take = lz + 1u; mode = M_LOW; }
 					}
-					else {
-						uint32_t sum = 0;
-#pragma unroll
-						for(int j = 0; j < FD_REGORD; j++) sum += (uint32_t)qr[j] * (uint32_t)hr[j];
-						x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift));
+					else if(mode == M_HDR) {
+						left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
+						part++;
+						k = hi >> (32u - plen); take = plen;
+						mode = k >= esc ? (uint32_t)M_RAWHDR : (left ? (uint32_t)M_TOKEN : (uint32_t)M_HDR);   // a first partition as long as the predictor order holds no residual
 					}
-#pragma unroll
-					for(int j = FD_REGORD - 1; j > 0; j--) hr[j] = hr[j - 1];
-					hr[0] = x;
+					else if(mode == M_LOW) {
+						const uint32_t low = k ? hi >> (32u - k) : 0u;
+						const uint32_t u = (qacc << k) | low;
+						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+						take = k; qacc = 0; have = true; mode = M_TOKEN;
+					}
+					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; }
+					else if(mode == M_RAW) { r = raw ? (int32_t)hi >> (32u - raw) : 0; take = raw; have = true; }
+					else { r = (int32_t)hi >> (32u - bps); take = bps; have = true; }   // verbatim sample
+					br.buf <<= take; br.avail -= take;
+					if(have) {
+						if(!(c.debug & 2u)) push(r);
+						todo--;
+						if(mode != M_VERB && --left == 0u) mode = M_HDR;
+					}
+					if(br.err) { ok = false; todo = 0; }
 				}
+				if((it & (FD_K - 1u)) == FD_K - 1u && !(c.debug & 8u)) hand_over(false);
+			}
+			hand_over(false);
+			if(ok && type >= 2u && part == 0) { const uint32_t k0 = br.read(plen); if(k0 >= esc) (void)br.read(5); }   // order == blocksize: the one partition is empty, its header is still there
+			if(ok && (br.err || br.bitpos() > c.nbytes * 8u)) ok = false;
+		}
+		hand_over(true);
+		if(parsed_header) {
+			if(ok) {
+				// zero padding to the byte boundary must be zero (:2779-2795), then the 16-bit CRC
+				const uint32_t pad = (uint32_t)((8u - (br.bitpos() & 7u)) & 7u);
+				if(pad && br.read(pad) != 0) { ex = 1; ok = false; }
 				else {
-					if(wide) { long long sum = 0; for(uint32_t j = 0; j < order; j++) sum += (long long)s_q[j][lane] * (long long)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)(int32_t)(sum >> shift)); }
-					else { uint32_t sum = 0; for(uint32_t j = 0; j < order; j++) sum += (uint32_t)s_q[j][lane] * (uint32_t)s_h[(hp - 1u - j) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)r + (uint32_t)((int32_t)sum >> shift)); }
-					s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
+					(void)br.read(16);
+					if(br.err || br.bitpos() > c.nbytes * 8u) ok = false;
 				}
-				out[i] = (int32_t)((uint32_t)x << wasted);
-				if(br.err) { ok = false; break; }
-				i++; left--;
 			}
-			if(!ok) break;
-			if(part == 0) { const uint32_t k0 = br.read(plen); if(k0 >= esc) (void)br.read(5); }   // order == blocksize: the one partition is empty, its header is still there
-		}
-		if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
-	}
-	if(ok) {
-		// zero padding to the byte boundary must be zero (:2779-2795), then the 16-bit CRC
-		const uint32_t pad = (uint32_t)((8u - (br.bitpos & 7u)) & 7u);
-		if(pad && br.read(pad) != 0) { ex = 1; ok = false; }
-		else {
-			(void)br.read(16);
-			if(br.err || br.bitpos > c.nbytes * 8u) ok = false;
+			if(!ok && (ex == 0 || br.err || br.bitpos() > c.nbytes * 8u)) ex = 6;
+			// cand_end: the byte just past the frame, or where the reference would look for the next sync code
+			// after giving the frame up (frame_sync_ first skips to the byte boundary, :1961-1965)
+			w.cand_end[ci] = (br.bitpos() + 7u) >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
+			w.cand_info[ci] = (ok ? 1u : 0u) | (h.assignment << 4) | (ex << 8);
 		}
 	}
-	if(!ok && (ex == 0 || br.err || br.bitpos > c.nbytes * 8u)) ex = 6;
-	(void)undefined;   // such a frame has a length like any other and its CRC-16 decides; were that to hold, the samples are as undefined here as there
-	// cand_end: the byte just past the frame, or where the reference would look for the next sync code
-	// after giving the frame up (frame_sync_ first skips to the byte boundary, :1961-1965)
-	info = (ok ? 1u : 0u) | (h.assignment << 4) | (ex << 8);
-	w.cand_end[ci] = (br.bitpos + 7u) >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
-	w.cand_info[ci] = info;
+	else {
+		// ================= restorer =================
+		// what the next item is: 0 blocksize, 1 subframe description, 2 warm-up sample, 3 residual description, 5 value, 6 nothing more
+		uint32_t st = live ? 0u : 6u, n = 0, ch = 0, i = 0, order = 0, wasted = 0, type = 0, shift = 0, wide = 0, nres = 0, hp = 0;
+		bool in_regs = true;
+		int32_t qr[FD_REGORD], hr[FD_REGORD];
+#pragma unroll
+		for(int j = 0; j < FD_REGORD; j++) { qr[j] = 0; hr[j] = 0; }
+		int32_t *out = w.ws;
+		uint32_t p = 0;
+		for(;;) {
+			__syncthreads();
+			const uint32_t cnt = pipe.cnt[p][lane];
+			const uint32_t more = __builtin_amdgcn_readfirstlane(pipe.more[p]);
+			for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
+				if(j < cnt && st != 6u && !(c.debug & 1u)) {
+					const int32_t v = pipe.buf[p][j][lane];
+					if(st == 5u) {
+						if(type == 0u) { const int32_t cv = (int32_t)((uint32_t)v << wasted); for(uint32_t t = 0; t < n; t++) out[t] = cv; }
+						else if(type == 1u) { if(i < n) out[i] = (int32_t)((uint32_t)v << wasted); i++; }
+						else {
+							int32_t x;
+							if(in_regs) {
+								if(wide) {
+									long long sum = 0;
+#pragma unroll
+									for(int t = 0; t < FD_REGORD; t++) sum += (long long)qr[t] * (long long)hr[t];
+									x = (int32_t)((uint32_t)v + (uint32_t)(int32_t)(sum >> shift));
+								}
+								else {
+									uint32_t sum = 0;
+#pragma unroll
+									for(int t = 0; t < FD_REGORD; t++) sum += (uint32_t)qr[t] * (uint32_t)hr[t];
+									x = (int32_t)((uint32_t)v + (uint32_t)((int32_t)sum >> shift));
+								}
+#pragma unroll
+								for(int t = FD_REGORD - 1; t > 0; t--) hr[t] = hr[t - 1];
+								hr[0] = x;
+							}
+							else {
+								if(wide) { long long sum = 0; for(uint32_t t = 0; t < order; t++) sum += (long long)s_qb[t][lane] * (long long)s_h[(hp - 1u - t) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)v + (uint32_t)(int32_t)(sum >> shift)); }
+								else { uint32_t sum = 0; for(uint32_t t = 0; t < order; t++) sum += (uint32_t)(int32_t)s_qb[t][lane] * (uint32_t)s_h[(hp - 1u - t) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)v + (uint32_t)((int32_t)sum >> shift)); }
+								s_h[hp & (FD_RING - 1u)][lane] = x; hp++;
+							}
+							if(i < n) out[i] = (int32_t)((uint32_t)x << wasted);
+							i++;
+						}
+						if(--nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
+					}
+					else if(st == 2u) {
+						if(i < n) out[i] = (int32_t)((uint32_t)v << wasted);
+						s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
+#pragma unroll
+						for(int t = FD_REGORD - 1; t > 0; t--) hr[t] = hr[t - 1];
+						hr[0] = v;
+						if(++i == order) st = 3u;
+					}
+					else if(st == 0u) { n = (uint32_t)v; ch = 0; st = 1u; }
+					else if(st == 1u) {
+						type = (uint32_t)v & 3u; order = ((uint32_t)v >> 2) & 63u; wasted = ((uint32_t)v >> 8) & 31u;
+						if(order > FD_RING) order = FD_RING;
+						i = 0; hp = 0;
+#pragma unroll
+						for(int t = 0; t < FD_REGORD; t++) { qr[t] = 0; hr[t] = 0; }
+						out = w.ws + ((size_t)ci * c.channels + ch) * c.ws_stride;
+						st = order ? 2u : 3u;
+					}
+					else { // st == 3: residual description
+						nres = (uint32_t)v & 0xffffu; shift = ((uint32_t)v >> 16) & 31u; wide = ((uint32_t)v >> 21) & 1u;
+						in_regs = order <= (uint32_t)FD_REGORD;
+						if(type == 3u) {
+							// the parser left the coefficients in its LDS column; it will not touch them before the next subframe head
+							for(uint32_t t = 0; t < order; t++) s_qb[t][lane] = s_q[t][lane];
+#pragma unroll
+							for(int t = 0; t < FD_REGORD; t++) qr[t] = ((uint32_t)t < order) ? (int32_t)s_q[t][lane] : 0;
+						}
+						else if(type == 2u) { // fixed.c:395-435
+							if(order == 1) { qr[0] = 1; }
+							else if(order == 2) { qr[0] = 2; qr[1] = -1; }
+							else if(order == 3) { qr[0] = 3; qr[1] = -3; qr[2] = 1; }
+							else if(order == 4) { qr[0] = 4; qr[1] = -6; qr[2] = 4; qr[3] = -1; }
+						}
+						if(nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; } else st = 5u;
+					}
+				}
+			}
+			p ^= 1u;
+			if(!more) break;
+		}
+	}
 }
 
 // CRC-16 over every parsed candidate, one workgroup per candidate.  The frame is cut into FD_CRC_THREADS
@@ -605,7 +747,7 @@ static size_t fd_align(size_t v) { return (v + 255) / 256 * 256; }
 extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_t channels, uint32_t bits_per_sample,
 	uint32_t max_blocksize, uint32_t max_frames, size_t max_bytes)
 {
-	if(!out || channels == 0 || channels > FLACAMD_MAX_CHANNELS || bits_per_sample < 4 || bits_per_sample > 24 || max_blocksize < 1 || max_blocksize > 65535 || max_frames == 0 || max_bytes == 0)
+	if(!out || channels == 0 || channels > FLACAMD_MAX_CHANNELS || bits_per_sample < 4 || bits_per_sample > 24 || max_blocksize < 1 || max_blocksize > 65535 || max_frames == 0 || max_bytes == 0 || max_bytes > ((size_t)1 << 33))   /* the bit reader counts 32-bit words in 32 bits */
 		return FLACAMD_E_INVALID_ARGUMENT;
 	*out = 0;
 	int ndev = 0;
@@ -666,6 +808,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	hipStream_t st = (hipStream_t)stream;
 	FD_TRY(hipSetDevice(d->device));
 	FdCfg c = d->cfg;
+	{ static const uint32_t dbg = getenv("FLACAMD_DECODE_DEBUG") ? (uint32_t)strtoul(getenv("FLACAMD_DECODE_DEBUG"), 0, 0) : 0u; c.debug = dbg; }
 	c.nbytes = nbytes; c.nscan_wg = (uint32_t)((nbytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES); c.pcm_format = (uint32_t)pcm_format; c.pcm_cap = pcm_cap_samples;
 	const uint8_t *bytes = (const uint8_t*)d_bytes;
 	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
@@ -680,7 +823,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 		return FLACAMD_E_BAD_STREAM;
 	}
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
-	hipLaunchKernelGGL(fd_decode_kernel, dim3((ncand + 63u) / 64u), dim3(64), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_decode_pipe_kernel, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
 	hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);
