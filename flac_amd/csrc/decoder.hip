@@ -417,25 +417,25 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				if(todo != 0u) {
 					br.refill();
 					const uint32_t hi = (uint32_t)(br.buf >> 32);
-					uint32_t take = 0; int32_t r = 0; bool have = false;
+					uint32_t take; int32_t r; bool have;
 					if(mode == M_TOKEN) {
+						// straight-line: a token that fits the upper word is the rule; the two other outcomes (32 zeros taken and
+						// the run goes on; the run ends here and the low bits come next step) fall out of the same values
 						const uint32_t lz = hi ? (uint32_t)__clz((int)hi) : 32u;
-						if(lz + k <= 31u) {
-							const uint32_t low = ((hi << lz) >> (31u - k)) & ((1u << k) - 1u);
-							const uint32_t u = ((qacc + lz) << k) | low;
-							r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-							take = lz + 1u + k; qacc = 0; have = true;
-						}
-						else if(lz == 32u) {
-							qacc += 32u; take = 32u;
-							if(qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u) { br.err = true; }
-						}
-						else { qacc += lz; take = lz + 1u; mode = M_LOW; }
+						const bool fits = lz + k <= 31u, run_on = lz == 32u;
+						const uint32_t low = ((hi << (lz & 31u)) >> ((31u - k) & 31u)) & ((1u << (k & 31u)) - 1u);
+						const uint32_t u = ((qacc + lz) << k) | low;
+						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+						have = fits;
+						take = fits ? lz + 1u + k : (run_on ? 32u : lz + 1u);
+						qacc = fits ? 0u : qacc + lz;
+						mode = (fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW;
+						if(run_on && (qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u)) br.err = true;
 					}
 					else if(mode == M_HDR) {
 						left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
 						part++;
-						k = hi >> (32u - plen); take = plen;
+						k = hi >> (32u - plen); take = plen; r = 0; have = false;
 						mode = k >= esc ? (uint32_t)M_RAWHDR : (left ? (uint32_t)M_TOKEN : (uint32_t)M_HDR);   // a first partition as long as the predictor order holds no residual
 					}
 					else if(mode == M_LOW) {
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
 						take = k; qacc = 0; have = true; mode = M_TOKEN;
 					}
-					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; }
+					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; r = 0; have = false; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; }
 					else if(mode == M_RAW) { r = raw ? (int32_t)hi >> (32u - raw) : 0; take = raw; have = true; }
 					else { r = (int32_t)hi >> (32u - bps); take = bps; have = true; }   // verbatim sample
 					br.buf <<= take; br.avail -= take;
