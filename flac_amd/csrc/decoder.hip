@@ -233,9 +233,9 @@ struct BitReader {
 	__device__ __forceinline__ uint32_t load_word(uint32_t wi)
 	{
 		if(wi >= wr) { fd_ring_fetch(ring, lane, b, nbytes, wr); wr += 4u; }   // ran dry between two top-ups (a very long token): fetch alone, out of line
-		return __builtin_bswap32(ring[wi & (FD_RING_WORDS - 1u)][lane]);
+		return ring[wi & (FD_RING_WORDS - 1u)][lane];   // as stored (little-endian load of big-endian data): swapped where it enters the window, so nothing waits for this read here
 	}
-	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)nextw << (32u - avail); avail += 32u; widx++; nextw = load_word(widx); } }
+	__device__ __forceinline__ void refill() { while(avail <= 32u) { buf |= (unsigned long long)__builtin_bswap32(nextw) << (32u - avail); avail += 32u; widx++; nextw = load_word(widx); } }
 	__device__ __forceinline__ void init(const uint8_t *base, uint64_t nb, uint64_t pos, uint32_t (*ring_)[64], uint32_t lane_)
 	{
 		b = base; nbytes = nb; widx = (uint32_t)(pos >> 2); buf = 0; avail = 0; err = false;
