@@ -148,9 +148,16 @@ def main():
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu = cpu_baseline(base)
 
+    # rehearsal of the N > 1 path on a box with one GPU: all ranks on device 0, rendezvous and reductions over gloo
+    rehearsal = os.environ.get("FLACAMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
@@ -190,7 +197,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
