@@ -38,7 +38,8 @@ struct FdCfg {
 };
 
 struct FdWork {
-	uint32_t *wg_count;     // [nscan_wg + 1] candidates per scan workgroup, then exclusive offsets
+	uint32_t *wg_count;     // [nscan_wg] candidates per scan workgroup
+	uint32_t *wg_off;       // [nscan_wg] their exclusive prefix sums
 	uint32_t *ncand;        // [1]
 	uint64_t *cand_pos;     // [max_frames]
 	uint64_t *cand_end;     // [max_frames] byte just past the frame
@@ -49,7 +50,7 @@ struct FdWork {
 	uint32_t *frame_of;     // [max_frames] candidate index of the r-th accepted frame
 	uint64_t *sample_off;   // [max_frames] first wide sample of the r-th accepted frame
 	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
-	const uint16_t *crc_tab;   // [256] CRC-16 byte table
+	const uint16_t *crc_tab;   // [4][256] CRC-16 of a byte followed by 0..3 zero bytes
 	const uint16_t *crc_segmul;// [256] x^(8 * crc_seg_bytes * j)
 };
 
@@ -140,34 +141,37 @@ __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict_
 	for(uint32_t i = 0; i < wv; i++) pre += s_wave[i];
 	if(!WRITE) { if(tid == 255u) w.wg_count[blockIdx.x] = pre + inc; }
 	else {
-		uint32_t at = w.wg_count[blockIdx.x] + pre + inc - cnt;
+		uint32_t at = w.wg_off[blockIdx.x] + pre + inc - cnt;
 		for(uint32_t k = 0; k < 16; k++) if(mask & (1u << k)) { if(at < c.max_frames) w.cand_pos[at] = p0 + k; at++; }
 	}
 }
 
 __global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w)
 {
-	__shared__ uint32_t wave_tot[16];
-	__shared__ uint32_t carry;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	if(tid == 0) carry = 0;
-	__syncthreads();
-	for(uint32_t base = 0; base < c.nscan_wg; base += 1024) {
-		const uint32_t i = base + tid;
-		const uint32_t v = i < c.nscan_wg ? w.wg_count[i] : 0u;
-		uint32_t inc = v;
+	// workgroup b owns scan workgroups [1024 b, 1024 b + 1024): it adds up every count ahead of them itself (coalesced,
+	// independent loads) and scans its own, so that no workgroup waits for another
+	__shared__ uint32_t wave_ahead[16], wave_own[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, b = blockIdx.x;
+	uint32_t ahead = 0;
+#pragma unroll 8
+	for(uint32_t i = 0; i < b; i++) ahead += w.wg_count[i * 1024u + tid];
+	const uint32_t i = b * 1024u + tid;
+	const uint32_t v = i < c.nscan_wg ? w.wg_count[i] : 0u;
+	uint32_t inc = v;
 #pragma unroll
-		for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
-		if(lane == 63u) wave_tot[wv] = inc;
-		__syncthreads();
-		uint32_t pre = carry;
-		for(uint32_t k = 0; k < wv; k++) pre += wave_tot[k];
-		if(i < c.nscan_wg) w.wg_count[i] = pre + inc - v;
-		__syncthreads();
-		if(tid == 1023u) carry = pre + inc;
-		__syncthreads();
+	for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
+#pragma unroll
+	for(int o = 32; o >= 1; o >>= 1) ahead += (uint32_t)__shfl_xor((int)ahead, o, 64);
+	if(lane == 63u) wave_own[wv] = inc;
+	if(lane == 0u) wave_ahead[wv] = ahead;
+	__syncthreads();
+	uint32_t base = 0;
+#pragma unroll
+	for(uint32_t k = 0; k < 16u; k++) { base += wave_ahead[k]; if(k < wv) base += wave_own[k]; }
+	if(i < c.nscan_wg) {
+		w.wg_off[i] = base + inc - v;
+		if(i + 1u == c.nscan_wg) w.ncand[0] = base + inc;
 	}
-	if(tid == 0) { w.ncand[0] = carry; }
 }
 
 // ---- speculative decode, one lane per candidate
@@ -585,13 +589,8 @@ __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *_
 	const uint32_t ci = blockIdx.x, tid = threadIdx.x;
 	const uint32_t info = w.cand_info[ci];
 	if(!(info & 1u)) return;
-	{
-		uint32_t v = w.crc_tab[tid];
-		tab[0][tid] = (uint16_t)v;
-		const uint16_t *t0 = w.crc_tab;
 #pragma unroll
-		for(int k = 1; k < 4; k++) { v = ((v << 8) & 0xffffu) ^ t0[v >> 8]; tab[k][tid] = (uint16_t)v; }
-	}
+	for(int k = 0; k < 4; k++) tab[k][tid] = w.crc_tab[256 * k + tid];   // four independent loads: the tables come ready from the host
 	__syncthreads();
 	const uint64_t pos = w.cand_pos[ci], end = w.cand_end[ci];
 	const uint64_t len = end - pos;
@@ -767,23 +766,24 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	const size_t nwg = (max_bytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES;
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = fd_align(off + bytes); return o; };
-	const size_t o_cnt = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
+	const size_t o_cnt = take((nwg + 1) * 4), o_woff = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
 		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * c.ws_stride * 4),
-		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(2048);
+		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(4096);
 	d->arena_bytes = off;
 	hipError_t he = hipMalloc(&d->arena, off);
 	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
 	uint8_t *b = (uint8_t*)d->arena;
 	FdWork &w = d->work;
-	w.wg_count = (uint32_t*)(b + o_cnt); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
+	w.wg_count = (uint32_t*)(b + o_cnt); w.wg_off = (uint32_t*)(b + o_woff); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
 	w.cand_info = (uint32_t*)(b + o_info); w.cand_bs = (uint32_t*)(b + o_bs); w.cand_num = (uint64_t*)(b + o_num); w.ws = (int32_t*)(b + o_ws);
 	w.frame_of = (uint32_t*)(b + o_fo); w.sample_off = (uint64_t*)(b + o_so); w.result = (uint64_t*)(b + o_res);
-	uint16_t tab[256 + 256];
+	uint16_t tab[1024 + 256];
 	for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }
-	{ unsigned v = 1; for(unsigned j = 0; j < 256; j++) { tab[256 + j] = (uint16_t)v; for(unsigned z = 0; z < c.crc_seg_bytes; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]; } }
+	for(unsigned z = 1; z < 4; z++) for(unsigned bb = 0; bb < 256; bb++) { const unsigned v = tab[256 * (z - 1) + bb]; tab[256 * z + bb] = (uint16_t)(((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]); }
+	{ unsigned v = 1; for(unsigned j = 0; j < 256; j++) { tab[1024 + j] = (uint16_t)v; for(unsigned z = 0; z < c.crc_seg_bytes; z++) v = ((v << 8) & 0xffffu) ^ tab[(v >> 8) & 0xffu]; } }
 	he = hipMemcpy(b + o_tab, tab, sizeof tab, hipMemcpyHostToDevice);
 	if(he != hipSuccess) { hipFree(d->arena); free(d); return FLACAMD_E_DEVICE; }
-	w.crc_tab = (const uint16_t*)(b + o_tab); w.crc_segmul = (const uint16_t*)(b + o_tab) + 256;
+	w.crc_tab = (const uint16_t*)(b + o_tab); w.crc_segmul = (const uint16_t*)(b + o_tab) + 1024;
 	*out = d;
 	return FLACAMD_OK;
 }
@@ -812,7 +812,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	c.nbytes = nbytes; c.nscan_wg = (uint32_t)((nbytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES); c.pcm_format = (uint32_t)pcm_format; c.pcm_cap = pcm_cap_samples;
 	const uint8_t *bytes = (const uint8_t*)d_bytes;
 	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
-	hipLaunchKernelGGL(fd_scan_offsets_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
+	hipLaunchKernelGGL(fd_scan_offsets_kernel, dim3((c.nscan_wg + 1023u) / 1024u), dim3(1024), 0, st, c, d->work);
 	hipLaunchKernelGGL(fd_scan_kernel<true>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
 	uint32_t ncand = 0;
 	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
