@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 // its remainder by x^(8 * bytes that follow it) and the remainders are XORed.  Leading zero bytes do not
 // change a CRC that starts at zero, so the one segment that sticks out in front of the frame is padded with zeros.
 #define FD_CRC_THREADS 256
-#define FD_CRC_MAXWORDS 16   // segments of up to 64 bytes stay in registers (frames up to 16 KB); longer ones take the byte loop
+#define FD_CRC_MAXWORDS 32   // segments of up to 128 bytes stay in registers (frames up to 32 KB: a verbatim 4096-sample stereo frame is 18.5 KB); longer ones take the byte loop
 __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
 	__shared__ uint16_t tab[4][256];   // tab[k][b]: remainder of byte b followed by k zero bytes
