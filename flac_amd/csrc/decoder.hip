@@ -422,25 +422,29 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					br.refill();
 					const uint32_t hi = (uint32_t)(br.buf >> 32);
 					uint32_t take; int32_t r; bool have;
-					if(mode == M_TOKEN) {
-						// straight-line: a token that fits the upper word is the rule; the two other outcomes (32 zeros taken and
-						// the run goes on; the run ends here and the low bits come next step) fall out of the same values
+					if(mode <= M_TOKEN) {
+						// Partition header or token, straight-line for both (which one a lane is at only picks among values that
+						// are cheap to form either way).  A token that fits the upper word is the rule; the two other outcomes
+						// (32 zeros taken and the run goes on; the run ends here and the low bits come next step) fall out of
+						// the same values.
+						const bool hdr = mode == M_HDR;
 						const uint32_t lz = hi ? (uint32_t)__clz((int)hi) : 32u;
 						const bool fits = lz + k <= 31u, run_on = lz == 32u;
 						const uint32_t low = ((hi << (lz & 31u)) >> ((31u - k) & 31u)) & ((1u << (k & 31u)) - 1u);
 						const uint32_t u = ((qacc + lz) << k) | low;
 						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-						have = fits;
-						take = fits ? lz + 1u + k : (run_on ? 32u : lz + 1u);
-						qacc = fits ? 0u : qacc + lz;
-						mode = (fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW;
-						if(run_on && (qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u)) br.err = true;
-					}
-					else if(mode == M_HDR) {
-						left = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
-						part++;
-						k = hi >> (32u - plen); take = plen; r = 0; have = false;
-						mode = k >= esc ? (uint32_t)M_RAWHDR : (left ? (uint32_t)M_TOKEN : (uint32_t)M_HDR);   // a first partition as long as the predictor order holds no residual
+						const uint32_t kh = hi >> (32u - plen);
+						const uint32_t left_h = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
+						have = !hdr && fits;
+						take = hdr ? plen : (fits ? lz + 1u + k : (run_on ? 32u : lz + 1u));
+						qacc = (hdr || fits) ? 0u : qacc + lz;
+						if(!hdr && run_on && (qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u)) br.err = true;
+						// a first partition as long as the predictor order holds no residual: its header is followed by the next header
+						mode = hdr ? (kh >= esc ? (uint32_t)M_RAWHDR : (left_h ? (uint32_t)M_TOKEN : (uint32_t)M_HDR))
+						           : ((fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW);
+						left = hdr ? left_h : left;
+						k = hdr ? kh : k;
+						part += hdr ? 1u : 0u;
 					}
 					else if(mode == M_LOW) {
 						const uint32_t low = k ? hi >> (32u - k) : 0u;
