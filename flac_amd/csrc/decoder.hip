@@ -40,6 +40,7 @@ struct FdCfg {
 struct FdWork {
 	uint32_t *wg_count;     // [nscan_wg] candidates per scan workgroup
 	uint32_t *wg_off;       // [nscan_wg] their exclusive prefix sums
+	uint16_t *scan_mask;    // [nscan_wg * 256] per scan thread: which of its 16 byte positions are candidates
 	uint32_t *ncand;        // [1]
 	uint64_t *cand_pos;     // [max_frames]
 	uint64_t *cand_end;     // [max_frames] byte just past the frame
@@ -117,18 +118,23 @@ __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict_
 	__shared__ uint32_t s_wave[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint64_t p0 = (uint64_t)blockIdx.x * FD_SCAN_BYTES + (uint64_t)tid * 16u;
-	// the thread's 16 bytes and the one after them in registers (one 16-byte load; the buffer is 16-byte aligned): positions
-	// that hold the two sync bytes are rare, only those go on to the header check
-	uint32_t wd[4] = {0, 0, 0, 0}, nxt = 0;
-	if(p0 + 16u <= c.nbytes) { const uint4 v = *(const uint4*)(b + p0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
-	else for(uint32_t k = 0; k < 16u; k++) if(p0 + k < c.nbytes) wd[k >> 2] |= (uint32_t)b[p0 + k] << (8u * (k & 3u));
-	if(p0 + 16u < c.nbytes) nxt = b[p0 + 16u];
 	uint32_t mask = 0;
+	const uint64_t ti = (uint64_t)blockIdx.x * 256u + tid;
+	if(WRITE) mask = w.scan_mask[ti];   // the counting pass left every thread's findings: the bytes are not read twice
+	else {
+		// the thread's 16 bytes and the one after them in registers (one 16-byte load; the buffer is 16-byte aligned): positions
+		// that hold the two sync bytes are rare, only those go on to the header check
+		uint32_t wd[4] = {0, 0, 0, 0}, nxt = 0;
+		if(p0 + 16u <= c.nbytes) { const uint4 v = *(const uint4*)(b + p0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
+		else for(uint32_t k = 0; k < 16u; k++) if(p0 + k < c.nbytes) wd[k >> 2] |= (uint32_t)b[p0 + k] << (8u * (k & 3u));
+		if(p0 + 16u < c.nbytes) nxt = b[p0 + 16u];
 #pragma unroll
-	for(uint32_t k = 0; k < 16; k++) {
-		const uint32_t b0 = (wd[k >> 2] >> (8u * (k & 3u))) & 0xffu;
-		const uint32_t b1 = k < 15u ? (wd[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xffu : nxt;
-		if(b0 == 0xffu && (b1 & 0xfeu) == 0xf8u && p0 + k + 1u < c.nbytes) { FdHeader h; if(fd_parse_header(b, c.nbytes, p0 + k, c, h)) mask |= 1u << k; }
+		for(uint32_t k = 0; k < 16; k++) {
+			const uint32_t b0 = (wd[k >> 2] >> (8u * (k & 3u))) & 0xffu;
+			const uint32_t b1 = k < 15u ? (wd[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xffu : nxt;
+			if(b0 == 0xffu && (b1 & 0xfeu) == 0xf8u && p0 + k + 1u < c.nbytes) { FdHeader h; if(fd_parse_header(b, c.nbytes, p0 + k, c, h)) mask |= 1u << k; }
+		}
+		w.scan_mask[ti] = (uint16_t)mask;
 	}
 	const uint32_t cnt = (uint32_t)__popc(mask);
 	// in-workgroup exclusive scan of the per-thread counts
@@ -770,7 +776,7 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	const size_t nwg = (max_bytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES;
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = fd_align(off + bytes); return o; };
-	const size_t o_cnt = take((nwg + 1) * 4), o_woff = take((nwg + 1) * 4), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
+	const size_t o_cnt = take((nwg + 1) * 4), o_woff = take((nwg + 1) * 4), o_mask = take(nwg * 256 * 2), o_nc = take(256), o_pos = take((size_t)max_frames * 8), o_end = take((size_t)max_frames * 8), o_info = take((size_t)max_frames * 4),
 		o_bs = take((size_t)max_frames * 4), o_num = take((size_t)max_frames * 8), o_ws = take((size_t)max_frames * channels * c.ws_stride * 4),
 		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(4096);
 	d->arena_bytes = off;
@@ -778,7 +784,7 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
 	uint8_t *b = (uint8_t*)d->arena;
 	FdWork &w = d->work;
-	w.wg_count = (uint32_t*)(b + o_cnt); w.wg_off = (uint32_t*)(b + o_woff); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
+	w.wg_count = (uint32_t*)(b + o_cnt); w.wg_off = (uint32_t*)(b + o_woff); w.scan_mask = (uint16_t*)(b + o_mask); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);
 	w.cand_info = (uint32_t*)(b + o_info); w.cand_bs = (uint32_t*)(b + o_bs); w.cand_num = (uint64_t*)(b + o_num); w.ws = (int32_t*)(b + o_ws);
 	w.frame_of = (uint32_t*)(b + o_fo); w.sample_off = (uint64_t*)(b + o_so); w.result = (uint64_t*)(b + o_res);
 	uint16_t tab[1024 + 256];
