@@ -640,6 +640,16 @@ __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *_
 		for(int i = 15; i >= 0; i--) { r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu; if((m >> i) & 1u) r ^= crc; }
 		crc = r;
 	}
+	else if(!fits) {
+		// a frame beyond the size bound the segments were laid out for (the reference writes such frames when a subframe's
+		// estimate wrapped): every thread takes an equal share byte by byte and raises x^8 to the bytes that follow it
+		const uint64_t share = (len + FD_CRC_THREADS - 1u) / FD_CRC_THREADS, a = share * tid < len ? share * tid : len, e = a + share < len ? a + share : len;
+		for(uint64_t i = a; i < e; i++) crc = ((crc << 8) & 0xffffu) ^ tab[0][(crc >> 8) ^ bytes[pos + i]];
+		auto mul = [](uint32_t x, uint32_t y) { uint32_t r = 0; for(int i = 15; i >= 0; i--) { r = (r & 0x8000u) ? ((r << 1) ^ 0x8005u) & 0xffffu : (r << 1) & 0xffffu; if((y >> i) & 1u) r ^= x; } return r; };
+		uint32_t pw = 1u, base = 0x100u;
+		for(uint64_t n = len - e; n; n >>= 1) { if(n & 1u) pw = mul(pw, base); base = mul(base, base); }
+		crc = mul(crc, pw);
+	}
 #pragma unroll
 	for(int o = 32; o > 0; o >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, o, 64);
 	if((tid & 63u) == 0) s_x[tid >> 6] = crc;
@@ -648,7 +658,7 @@ __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *_
 	if(tid == 0) {
 		uint32_t all = 0;
 		for(uint32_t k = 0; k < FD_CRC_THREADS / 64; k++) all ^= s_x[k];
-		if(fits && all == 0) w.cand_info[ci] = info | 2u;
+		if(all == 0) w.cand_info[ci] = info | 2u;
 	}
 }
 

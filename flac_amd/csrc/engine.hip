@@ -22,6 +22,7 @@ size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg);
 void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st);
 size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out);
 void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+void fa_launch_pack_general(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, int large);
 void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st);
 }
 
@@ -247,6 +248,13 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	e->cand_group = c.max_cand < 24u ? c.max_cand : 24u;
 	if(e->cand_group == 0) e->cand_group = 1;
 	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
+	// LDS of the general kernels: fewer candidates per pass, then the signal out of LDS, until a workgroup's tables fit
+	while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
+	if((fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u || fa_pack_lds_bytes(&c, 0) > 160u * 1024u) && !c.spill) {
+		c.spill = 1u;
+		e->cand_group = c.max_cand < 24u ? (c.max_cand ? c.max_cand : 1u) : 24u;
+		while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
+	}
 	if(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }
 	if(fa_pack_lds_bytes(&c, 0) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }
 
@@ -259,7 +267,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
+		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
 		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
@@ -277,6 +285,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		uint32_t words = 0;
 		fa_pack_lds_bytes(&c, &words);
 		if(words < c.slot_bytes / 4u + 2u) words = c.slot_bytes / 4u + 2u;   // x^(32 w) up to a whole frame
+		if(words < FA_PACK_LARGE_WORDS + 512u) words = FA_PACK_LARGE_WORDS + 512u;   // and up to the second pass's bit buffer
 		uint16_t *tab = (uint16_t*)malloc(sizeof(uint16_t) * (1024u + words + 1u));
 		if(!tab) { hipFree(e->arena); free(e); return FLACAMD_E_OUT_OF_MEMORY; }
 		for(unsigned bb = 0; bb < 256; bb++) { unsigned v = bb << 8; for(int i = 0; i < 8; i++) v = (v & 0x8000u) ? ((v << 1) ^ 0x8005u) & 0xffffu : (v << 1) & 0xffffu; tab[bb] = (uint16_t)v; }
@@ -360,6 +369,32 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
 }
 
+// A frame did not fit its slot.  Slots are sized for a verbatim frame with slack, and the encoder only keeps a subframe
+// whose ESTIMATE beats verbatim - but the reference's partition sums wrap at 32 bits where it takes them narrow
+// (stream_encoder.c:3808), so on full-scale noise of wide samples an estimate can fall far short of the size and the
+// reference then writes a frame several times the verbatim size.  To write the same frame: the pack and gather stages
+// once more with slots 16 times as large, through the general pack kernel (which flushes in the middle of a subframe).
+static int repack_long(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint32_t *status, uint64_t *total, hipStream_t st)
+{
+	size_t big = (size_t)c.slot_bytes * 16u;
+	if(big > ((size_t)1 << 24)) big = (size_t)1 << 24;   // a frame size has 24 bits in STREAMINFO (format.c:72)
+	if(big <= c.slot_bytes) return FLACAMD_E_FRAME_OVERFLOW;
+	void *tmp = 0;
+	if(hipMalloc(&tmp, (size_t)c.F * big) != hipSuccess) { (void)hipGetLastError(); return FLACAMD_E_FRAME_OVERFLOW; }
+	FaCfg cc = c; FaWork ww = e->work;
+	cc.slot_bytes = (uint32_t)big; ww.slots = (uint8_t*)tmp;
+	hipError_t he = hipMemsetAsync(e->work.status, 0, 4, st);
+	fa_launch_pack_general(d_pcm, &cc, &ww, st, 1);
+	fa_launch_gather(&cc, &ww, d_out, out_cap, d_frame_bytes, st);
+	if(he == hipSuccess) he = hipGetLastError();
+	if(he == hipSuccess) he = hipMemcpyAsync(status, e->work.status, 4, hipMemcpyDeviceToHost, st);
+	if(he == hipSuccess) he = hipMemcpyAsync(total, e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, st);
+	if(he == hipSuccess) he = hipStreamSynchronize(st);
+	(void)hipFree(tmp);
+	if(he != hipSuccess) return hip_fail(he, "repack_long");
+	return FLACAMD_OK;
+}
+
 // The stages of one batch on stream st; synchronises once at the end to read the status word and the total.
 static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st)
 {
@@ -397,7 +432,8 @@ static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void
 	HIP_TRY(hipMemcpyAsync(&total, e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	if(tm) { for(int i = 0; i < 6; i++) hipEventElapsedTime(&e->last_ms[i], e->ev[i], e->ev[i+1]); e->have_timing = 1; }
-	if(h_total_bytes) *h_total_bytes = total;
+	if(status & 1u) { const int rc2 = repack_long(e, c, d_pcm, d_out, out_cap, d_frame_bytes, &status, &total, st); if(rc2 != FLACAMD_OK) return rc2; }
+	if(h_total_bytes) *h_total_bytes = total;   // with FLACAMD_E_CAPACITY: the bytes the output buffer needs
 	if(status & 1u) return FLACAMD_E_FRAME_OVERFLOW;
 	if(status & 2u) return FLACAMD_E_CAPACITY;
 	return FLACAMD_OK;
@@ -473,9 +509,17 @@ extern "C" int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pc
 	HIP_TRY(hipMemcpy(e->d_pcm_stage, h_pcm, pcm_bytes, hipMemcpyHostToDevice));
 	uint64_t total = 0;
 	int rc = flacamd_encode_device(e, e->d_pcm_stage, pcm_format, nsamples, final_block, first_frame_number, prev_assignment,
-		e->d_out_stage, need_out, e->d_fb_stage, &total, 0);
+		e->d_out_stage, e->out_stage_bytes, e->d_fb_stage, &total, 0);
+	if(rc == FLACAMD_E_CAPACITY && total > e->out_stage_bytes) {   // frames beyond the usual bound (see repack_long): a larger staging buffer, once more
+		hipFree(e->d_out_stage); e->d_out_stage = 0; e->out_stage_bytes = 0;
+		HIP_TRY(hipMalloc((void**)&e->d_out_stage, total));
+		e->out_stage_bytes = total;
+		rc = flacamd_encode_device(e, e->d_pcm_stage, pcm_format, nsamples, final_block, first_frame_number, prev_assignment,
+			e->d_out_stage, e->out_stage_bytes, e->d_fb_stage, &total, 0);
+	}
+	if(h_total_bytes) *h_total_bytes = total;
 	if(rc != FLACAMD_OK) return rc;
-	if(total > out_cap) return FLACAMD_E_CAPACITY;
+	if(total > out_cap) return FLACAMD_E_CAPACITY;   // *h_total_bytes tells the caller how much it takes
 	HIP_TRY(hipMemcpy(h_out, e->d_out_stage, total, hipMemcpyDeviceToHost));
 	if(h_frame_bytes) HIP_TRY(hipMemcpy(h_frame_bytes, e->d_fb_stage, (size_t)F * 4u, hipMemcpyDeviceToHost));
 	if(h_last_assignment) HIP_TRY(hipMemcpy(h_last_assignment, e->work.assignment + (F - 1), 4, hipMemcpyDeviceToHost));

@@ -8,6 +8,7 @@
 #define FA_MAX_QLP_PRECISION 15u
 #define FA_MAX_PARTS (1u << FLACAMD_MAX_PARTITION_ORDER)
 #define FA_DBG_WORDS 131072u
+#define FA_PACK_LARGE_WORDS 38000u   // bit buffer of the pack stage's second pass (frames far beyond the verbatim size)
 #define FA_LDS_BLOCKSIZE 16384u   // largest block whose padded 32-bit signal shares LDS with the other per-workgroup tables
 
 // subframe kinds (bitstream order of the type codes)

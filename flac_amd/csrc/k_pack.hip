@@ -894,6 +894,8 @@ static uint32_t fa_pack_fast_words(const FaCfg *c)
 	return (uint32_t)((16u * 8u + c->channels * sub + 64u + 31u) / 32u) + 4u;
 }
 
+extern "C" void fa_launch_pack_general(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, int large);
+
 extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
 	if(fa_pack_fast_ok(pcm, c)) {
@@ -911,8 +913,22 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 		}
 		return;
 	}
+	fa_launch_pack_general(pcm, c, w, st, 0);
+}
+
+// the general kernel for any stream: one subframe at a time through LDS, flushed whenever the next tokens might not fit.
+// large: as much bit buffer as LDS holds (FA_PACK_LARGE_WORDS at most), for frames far beyond the verbatim size: the
+// 4096 tokens of one round have to fit between two flushes.
+extern "C" void fa_launch_pack_general(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, int large)
+{
 	uint32_t words = 0;
-	const size_t lds = fa_pack_lds_bytes(c, &words);
+	size_t lds = fa_pack_lds_bytes(c, &words);
+	if(large) {
+		const size_t xsb = c->spill ? 0u : (size_t)xs_words_for(c->N) * 4u;
+		const size_t room = 150u * 1024u > xsb ? (150u * 1024u - xsb) / 4u : 0u;
+		if(room > words) words = room > FA_PACK_LARGE_WORDS ? FA_PACK_LARGE_WORDS : (uint32_t)room;
+		lds = (xsb + (size_t)words * 4u + 15u) & ~(size_t)15u;
+	}
 	if(c->spill) {
 		(void)hipFuncSetAttribute((const void*)fa_pack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(fa_pack_kernel<true>, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);

@@ -312,6 +312,7 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 	d->decode_pos = d->first_frame_offset;
 	if(!d->eng) {
 		max_frame = 16 + (size_t)si->channels * (((size_t)si->max_blocksize * (si->bits_per_sample + 2) + 7) / 8 + 64) + 2;
+		if(si->max_framesize + 16u > max_frame) max_frame = (size_t)si->max_framesize + 16u;   /* the stream says its frames are longer than the usual bound */
 		d->batch_bytes = max_frame * d->batch_frames;
 		if(d->batch_bytes < ((size_t)1 << 16)) d->batch_bytes = (size_t)1 << 16;
 		/* the device decoder's capacity counts every candidate that passes the header checks, and a

@@ -531,8 +531,19 @@ static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final
 {
 	uint64_t total = 0; uint32_t last = 0; size_t off = 0; unsigned f;
 	const unsigned N = e->p.blocksize, nframes = (unsigned)((nsamples + N - 1) / N);
-	const int rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
+	int rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
 		e->out, e->out_cap, e->frame_bytes, &total, &last);
+	if(rc == FLACAMD_E_CAPACITY && total > e->out_cap) { /* frames beyond the usual bound (a subframe whose estimate wrapped): a buffer of the size the engine names */
+		uint8_t *nb = (uint8_t*)realloc(e->out, (size_t)total);
+		if(!nb) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		e->out = nb; e->out_cap = (size_t)total;
+		if(e->vdec) { /* the verify decoder takes a batch of that size too */
+			flacamd_decoder_destroy(e->vdec); e->vdec = 0;
+			if(flacamd_decoder_create(&e->vdec, e->device, e->p.channels, e->p.bits_per_sample, e->p.blocksize, 2 * e->batch_frames + 256, e->out_cap) != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		}
+		rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
+			e->out, e->out_cap, e->frame_bytes, &total, &last);
+	}
 	if(rc != FLACAMD_OK) { e->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR; return 0; }
 	e->last_assignment = last;
 	if(e->verify) { /* write_bitbuffer_ verifies a frame before it is written (:2396-2411): stop ahead of the first bad one */

@@ -178,8 +178,14 @@ class Encoder:
         fb = np.zeros(F, dtype=np.uint32)
         total = C.c_uint64(0)
         last = C.c_uint32(0)
-        _check(self._lib.flacamd_encode_host(self._h, pcm.ctypes.data, fmt, n, 1 if final else 0, first_frame, prev_assignment,
-                                              out.ctypes.data, cap, fb.ctypes.data, C.byref(total), C.byref(last)), "flacamd_encode_host")
+        rc = self._lib.flacamd_encode_host(self._h, pcm.ctypes.data, fmt, n, 1 if final else 0, first_frame, prev_assignment,
+                                           out.ctypes.data, cap, fb.ctypes.data, C.byref(total), C.byref(last))
+        if rc == -6 and total.value > cap:   # frames beyond the usual bound: the call says how many bytes it takes
+            cap = int(total.value)
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self._lib.flacamd_encode_host(self._h, pcm.ctypes.data, fmt, n, 1 if final else 0, first_frame, prev_assignment,
+                                               out.ctypes.data, cap, fb.ctypes.data, C.byref(total), C.byref(last))
+        _check(rc, "flacamd_encode_host")
         frames, off = [], 0
         for s in fb:
             frames.append(bytes(out[off:off + int(s)]))

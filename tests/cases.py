@@ -34,6 +34,13 @@ def parity_cases(small=False):
         ("mono16-5-bs40000", lambda: _music(2.0, 62, 1), 1, 16, 44100, dict(level=5, blocksize=40000)),
         ("white24-bs65535", lambda: synth.white_noise(140000, 2, 24, seed=8), 2, 24, 96000, dict(level=8, blocksize=65535)),
         ("white16-bs60000", lambda: synth.white_noise(130000, 2, 16, seed=9), 2, 16, 44100, dict(level=5, blocksize=60000)),
+        # full-scale 24-bit noise: a narrow partition sum of the reference wraps, the estimate of a fixed subframe falls far
+        # short and the frame comes out at twice the verbatim size (the engine's second pass with large slots)
+        ("noise24-wrapped-estimate", lambda: np.random.default_rng(3).integers(-7300000, 7300000, (3000, 2)).astype(np.int32), 2, 24, 48000,
+         dict(level=8, blocksize=1000, max_residual_partition_order=4)),
+        # tables of the general search kernel beyond LDS unless the candidates go in smaller groups
+        ("6ch12-bs16384-p-r8", lambda: (synth.multichannel_24(0.3, channels=6, seed=12)[:20467] >> 12).astype(np.int32), 6, 12, 96000,
+         dict(level=8, blocksize=16384, do_qlp_coeff_prec_search=1, max_residual_partition_order=8)),
         ("st16-8-l32", lambda: _music(s / 2, 29), 2, 16, 44100, dict(level=8, max_lpc_order=32)),
         ("st16-8-l32-p", lambda: _music(0.3, 30), 2, 16, 44100, dict(level=8, max_lpc_order=32, do_qlp_coeff_prec_search=1)),
         ("st16-8-r8", lambda: _music(s / 2, 31), 2, 16, 44100, dict(level=8, max_residual_partition_order=8)),

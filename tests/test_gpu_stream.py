@@ -120,6 +120,30 @@ def test_long_blocks_outside_the_subset(gpu_engine, bs, level, bps, n):
     d.close()
 
 
+def test_frames_beyond_the_verbatim_size(gpu_engine):
+    """Full-scale 24-bit noise: a narrow partition sum of the reference wraps (stream_encoder.c:3808), the estimate of a
+    fixed subframe falls far short and the reference writes a frame of twice the verbatim size.  The same stream has to
+    come out of the encoder object (second pack pass with large slots, output buffer grown), verified, and decode again."""
+    if not ob.have_ref():
+        pytest.skip("oracle/_ref not built")
+    pcm = np.random.default_rng(3).integers(-7300000, 7300000, (3000, 2)).astype(np.int32)
+    _, rp = ob.make_params(2, 24, 48000, level=8, blocksize=1000, max_residual_partition_order=4)
+    ref = ob.ref_encode(rp, pcm)
+    assert max(len(f) for f in ref["frames"]) > 1000 * 2 * 3 * 3 // 2       # the case is what it says
+    e = stream.MemoryEncoder(seekable=False)
+    _configure(e, 2, 24, 48000, dict(level=8, blocksize=1000, max_residual_partition_order=4))
+    assert e.set_verify(1) and e.set_batch_frames(2)
+    assert e.init() == stream.INIT_OK
+    _feed(e, pcm, 1234)
+    assert e.finish()
+    assert bytes(e.buf) == ref["stream"]
+    e.close()
+    d = stream.StreamDecoder(ref["stream"], seekable=False)
+    assert d.init() == 0 and d.process_until_end_of_stream() and d.errors == []
+    assert np.array_equal(d.pcm(), pcm)
+    d.close()
+
+
 def test_file_encoder_matches_reference_tool(gpu_engine, tmp_path):
     """init_file + progress callback; byte-for-byte the file the reference's flac tool writes."""
     if not os.path.exists(ob.REF_FLAC):
