@@ -53,6 +53,16 @@ def main():
             kw["qlp_coeff_precision"] = int(rng.integers(5, 16))
         if rng.integers(8) == 0:
             kw["do_exhaustive_model_search"] = 1
+        if rng.integers(8) == 0:
+            kw["apodization"] = [("tukey", 0.25), ("hann", 0), ("blackman", 0)][:int(rng.integers(1, 4))]
+        if rng.integers(10) == 0:
+            kw["disable_fixed"] = 1
+        if rng.integers(10) == 0:
+            kw["disable_verbatim"] = 1
+        if rng.integers(10) == 0:
+            kw["disable_constant"] = 1
+        if rng.integers(8) == 0:
+            kw["min_residual_partition_order"] = int(rng.integers(0, 5))
         eff = bs or (4096 if kw.get("max_lpc_order", 1 if level >= 3 else 0) else 1152)
         n = int(rng.integers(1, 4)) * eff + int(rng.integers(0, eff))
         n = min(n, 70000)
@@ -67,6 +77,14 @@ def main():
             enc, (frames, _) = tp._encode(engine, ch, bps, rate, kw, pcm)
             enc.close()
             same = frames == want
+            if same:   # and back through the device decoder
+                blob = b"".join(want)
+                dec = engine.Decoder(ch, bps, max(eff, 16), max_frames=len(want) + 64, max_bytes=len(blob) + 64)
+                back, info = dec.decode_host(blob, n + eff)
+                dec.close()
+                if info["frames"] != len(want) or not np.array_equal(back, pcm):
+                    same = False
+                    print("seed", seed, "decoder differs")
             if same and bps <= 16:
                 enc, (frames16, _) = tp._encode(engine, ch, bps, rate, kw, pcm.astype(np.int16))
                 enc.close()
