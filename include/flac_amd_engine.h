@@ -110,7 +110,11 @@ size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nfram
  *   d_frame_bytes  device array [nframes]: size of each frame
  *   h_total_bytes  host: receives the total (this call synchronises the stream once at
  *                  its end to read it and the status word); may be NULL
- * Returns 0 or a negative error; on FLACAMD_E_FRAME_OVERFLOW no output is valid. */
+ * Returns 0 or a negative error; on FLACAMD_E_FRAME_OVERFLOW no output is valid.
+ * flacamd_encoder_max_output_bytes() covers every frame whose size stays within the verbatim bound.  The reference
+ * can write larger ones (a subframe is kept on its estimate, and its narrow partition sums wrap on full-scale noise of
+ * wide samples, stream_encoder.c:3808); such a batch is coded in a second pass and, when out_cap is too small for it,
+ * the call returns FLACAMD_E_CAPACITY with the bytes it takes in *h_total_bytes: call again with a buffer of that size. */
 int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
 	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream);
