@@ -65,7 +65,12 @@ def encode_clips(clips, level=5, device=0):
         cap = enc.max_output_bytes(total_frames)
         d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
         d_fb = torch.empty(total_frames, dtype=torch.int32, device=dev)
-        total = enc.encode_streams_device(d_pcm.data_ptr(), fmt, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
+        try:
+            total = enc.encode_streams_device(d_pcm.data_ptr(), fmt, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
+        except engine.OutputTooSmall as big:   # frames beyond the verbatim bound (the reference writes them too)
+            cap = big.needed
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            total = enc.encode_streams_device(d_pcm.data_ptr(), fmt, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
         enc.close()
         results.append((d_out[:total].cpu().numpy(), d_fb.cpu().numpy()))
     # ---- phase 3: digests, stream heads, assembly

@@ -207,8 +207,11 @@ class Encoder:
         st = np.ascontiguousarray(starts, dtype=np.uint64)
         ln = np.ascontiguousarray(lengths, dtype=np.uint64)
         total = C.c_uint64(0)
-        _check(self._lib.flacamd_encode_streams_device(self._h, d_pcm_ptr, fmt, len(st), st.ctypes.data, ln.ctypes.data, d_out_ptr, out_cap,
-                                                        d_frame_bytes_ptr, C.byref(total), stream), "flacamd_encode_streams_device")
+        rc = self._lib.flacamd_encode_streams_device(self._h, d_pcm_ptr, fmt, len(st), st.ctypes.data, ln.ctypes.data, d_out_ptr, out_cap,
+                                                     d_frame_bytes_ptr, C.byref(total), stream)
+        if rc == -6 and total.value > out_cap:
+            raise OutputTooSmall(int(total.value))   # frames beyond the verbatim bound: call again with that many bytes
+        _check(rc, "flacamd_encode_streams_device")
         return int(total.value)
 
     def debug(self, what, dtype, count):
@@ -221,6 +224,14 @@ class Encoder:
 
 def device_count():
     return int(lib().flacamd_device_count())
+
+
+class OutputTooSmall(Exception):
+    """The batch holds frames beyond the usual size bound; .needed is the output size in bytes to call again with."""
+
+    def __init__(self, needed):
+        super().__init__("output buffer too small: %d bytes needed" % needed)
+        self.needed = needed
 
 
 class Decoder:
