@@ -73,3 +73,47 @@ def test_streams_in_one_pass_equal_streams_alone(gpu_engine, ch, bps, level, kw)
     with pytest.raises(engine.EngineError):
         enc.encode_streams_device(d_pcm.data_ptr(), fmt, [0], [0], d_out.data_ptr(), cap, d_fb.data_ptr())
     enc.close()
+
+
+def test_a_frame_beyond_the_verbatim_size_inside_a_batch(gpu_engine):
+    """One of the streams of the batch holds a frame of about twice the verbatim size (full-scale 24-bit noise: a narrow
+    partition sum of the reference wraps, stream_encoder.c:3808): the call names the output size it takes, and the
+    frames of all streams equal the oracle's."""
+    import oracle_bindings as ob
+    kw = dict(level=8, blocksize=1000, max_residual_partition_order=4)
+    fp, _ = ob.make_params(2, 24, 48000, **kw)
+    params = engine.make_params(2, 24, 48000, **kw)
+    rng = np.random.default_rng(1)
+    streams = [rng.integers(-20000, 20000, (2500, 2)).astype(np.int32),
+               np.random.default_rng(3).integers(-7300000, 7300000, (3000, 2)).astype(np.int32),
+               rng.integers(-2000, 2000, (1000, 2)).astype(np.int32)]
+    want = []
+    for pcm in streams:
+        want += ob.oracle_encode(fp, pcm)["frames"]
+    assert max(len(f) for f in want) > 9000
+    lens = [len(s) for s in streams]
+    nfr = [-(-n // 1000) for n in lens]
+    starts = np.cumsum([0] + [f * 1000 for f in nfr])[:-1]
+    host = np.zeros((sum(nfr) * 1000, 2), np.int32)
+    for st, pcm in zip(starts, streams):
+        host[st:st + len(pcm)] = pcm
+    d_pcm = torch.from_numpy(host).cuda()
+    F = sum(nfr)
+    enc = engine.Encoder(params, max_frames=F)
+    cap = 8 * 1024      # far too small on purpose
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    d_fb = torch.empty(F, dtype=torch.int32, device="cuda")
+    with pytest.raises(engine.OutputTooSmall) as big:
+        enc.encode_streams_device(d_pcm.data_ptr(), engine.PCM_S32, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
+    cap = big.value.needed
+    assert cap == sum(len(f) for f in want)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total = enc.encode_streams_device(d_pcm.data_ptr(), engine.PCM_S32, starts, lens, d_out.data_ptr(), cap, d_fb.data_ptr())
+    enc.close()
+    sizes = d_fb.cpu().numpy()
+    data = d_out[:total].cpu().numpy().tobytes()
+    got, off = [], 0
+    for s in sizes:
+        got.append(data[off:off + int(s)])
+        off += int(s)
+    assert got == want
