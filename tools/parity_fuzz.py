@@ -92,6 +92,8 @@ def main():
         except Exception as ex:
             same = False
             print("seed", seed, "exception", repr(ex)[:200])
+        if seed % 500 == 499:
+            print("... seed", seed, "differing so far", bad, flush=True)
         if not same:
             bad += 1
             print("seed", seed, "differs: ch", ch, "bps", bps, "rate", rate, kw, "n", n, flush=True)
