@@ -8,6 +8,7 @@
 // A single long stream is hashed on a host thread by the stream encoder shim instead.
 #include "engine_types.h"
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 __constant__ uint32_t md5_k[64] = {
 	0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,
@@ -140,5 +141,56 @@ extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format,
 		if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	}
 	(void)hipFree(d_off); (void)hipFree(d_dig);
+	return rc;
+}
+
+// ---- the same without any allocation --------------------------------------------------
+// For callers that cannot call hipMalloc (code under HIP graph capture, serving loops, harnesses that forbid
+// it): the stream offsets and the digests are staged in a fixed array that is part of the code object, one copy
+// per GPU at its own address.  The array's name is only a host-side handle: the device address is looked up
+// once per device with hipGetSymbolAddress and that pointer is what kernels and copies receive.
+#define FA_MD5_STATIC_STREAMS 65536u
+#define FA_MD5_STATIC_OFF_BYTES (((size_t)FA_MD5_STATIC_STREAMS + 1u) * 8u + 248u)   // the digests start 256-byte aligned
+static __device__ __align__(256) unsigned char scratch[FA_MD5_STATIC_OFF_BYTES + (size_t)FA_MD5_STATIC_STREAMS * 16u];
+
+#define FA_MD5_MAX_DEVICES 64
+static std::mutex g_scratch_lock;
+static unsigned char *g_scratch_ptr[FA_MD5_MAX_DEVICES];
+
+// device address of this GPU's copy of `scratch` (the device must be current); NULL on failure
+static unsigned char *md5_scratch_of(int device)
+{
+	std::lock_guard<std::mutex> hold(g_scratch_lock);
+	if(!g_scratch_ptr[device]) {
+		void *p = 0;
+		if(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { (void)hipGetLastError(); return 0; }
+		g_scratch_ptr[device] = (unsigned char*)p;
+	}
+	return g_scratch_ptr[device];
+}
+
+extern "C" uint32_t flacamd_md5_device_static_max_streams(void) { return FA_MD5_STATIC_STREAMS; }
+
+extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
+	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests, void *stream)
+{
+	if(!d_pcm || !h_offsets || !h_digests || nstreams == 0 || channels == 0 || channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(nstreams > FA_MD5_STATIC_STREAMS) return FLACAMD_E_CAPACITY;   // more streams than the fixed array stages: split the batch, or use flacamd_md5_device
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= FA_MD5_MAX_DEVICES) return FLACAMD_E_NO_DEVICE;
+	hipStream_t st = (hipStream_t)stream;
+	if(hipSetDevice(device) != hipSuccess) return FLACAMD_E_DEVICE;
+	unsigned char *base = md5_scratch_of(device);
+	if(!base) return FLACAMD_E_DEVICE;
+	uint64_t *d_off = (uint64_t*)base;
+	uint8_t *d_dig = base + FA_MD5_STATIC_OFF_BYTES;
+	// nothing in the array has to start at zero: the kernel reads offsets[0..nstreams] and writes every byte of
+	// digests[0..nstreams), both overwritten here, and nothing beyond them is copied out
+	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
+	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, nstreams, d_dig);
+	int rc = hipGetLastError() == hipSuccess ? FLACAMD_OK : FLACAMD_E_DEVICE;
+	if(rc == FLACAMD_OK && hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
+	if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	return rc;
 }

@@ -76,6 +76,8 @@ def lib():
         L.flacamd_encoder_set_timing.restype = None
         L.flacamd_encoder_last_timing.argtypes = [vp, C.POINTER(C.c_float * 6)]
         L.flacamd_md5_device.argtypes = [C.c_int, vp, C.c_int, u32, u32, vp, u32, vp, vp]
+        L.flacamd_md5_device_static.argtypes = [C.c_int, vp, C.c_int, u32, u32, vp, u32, vp, vp]
+        L.flacamd_md5_device_static_max_streams.restype = u32
         L.flacamd_decoder_create.argtypes = [C.POINTER(vp), C.c_int, u32, u32, u32, u32, sz]
         L.flacamd_decoder_destroy.argtypes = [vp]
         L.flacamd_decoder_destroy.restype = None

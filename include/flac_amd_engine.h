@@ -158,6 +158,17 @@ int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6]);
 int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
 	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests /* [nstreams][16] */, void *stream);
 
+/* flacamd_md5_device without any allocation.  No counterpart in the reference: it is for callers that
+ * cannot allocate device memory - code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments and results as flacamd_md5_device; the stream offsets and the digests are staged
+ * in a fixed array inside the library (one copy per GPU, about 1.5 MiB, held until the process ends), so
+ * nstreams is limited to flacamd_md5_device_static_max_streams() = 65536 (FLACAMD_E_CAPACITY beyond that)
+ * and the call makes no hipMalloc / hipFree.  All calls on one GPU share that array: calls that overlap on
+ * the same GPU race, serialise them. */
+int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
+	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests /* [nstreams][16] */, void *stream);
+uint32_t flacamd_md5_device_static_max_streams(void);
+
 /* ---- decoder ---------------------------------------------------------------------- */
 
 /* Decoder for streams of known channels / bits_per_sample / max blocksize (from STREAMINFO). */
