@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -212,7 +215,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	int rc = flacamd_params_resolve(&e->p);
 	if(rc != FLACAMD_OK) { free(e); return rc; }
 	e->device = device; e->max_frames = max_frames;
-	HIP_TRY(hipSetDevice(device));
+	{ hipError_t e0 = hipSetDevice(device); if(e0 != hipSuccess) { free(e); return hip_fail(e0, "hipSetDevice"); } }
 
 	const flacamd_params &p = e->p;
 	FaCfg &c = e->cfg;
@@ -395,8 +398,8 @@ static int repack_long(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, vo
 	return FLACAMD_OK;
 }
 
-// The stages of one batch on stream st; synchronises once at the end to read the status word and the total.
-static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st)
+// The stages of one batch on stream st, nothing else: no readback, no synchronisation.
+static int enqueue_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, hipStream_t st)
 {
 	e->last_F = c.F; e->last_G = c.G;
 
@@ -426,7 +429,15 @@ static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void
 	fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
 	if(tm) hipEventRecord(e->ev[6], st);
 	HIP_TRY(hipGetLastError());
+	return FLACAMD_OK;
+}
 
+// One batch on stream st; synchronises once at the end to read the status word and the total.
+static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st)
+{
+	const int rc = enqueue_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, st);
+	if(rc != FLACAMD_OK) return rc;
+	const bool tm = e->timing != 0;
 	uint32_t status = 0; uint64_t total = 0;
 	HIP_TRY(hipMemcpyAsync(&status, e->work.status, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&total, e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, st));
@@ -560,6 +571,314 @@ extern "C" long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h
 	if(bytes > cap) return FLACAMD_E_CAPACITY;
 	if(hipMemcpy(h_dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return FLACAMD_E_DEVICE;
 	return (long)bytes;
+}
+
+// ------------------------------------------------------------------ pipelined encoding from host memory
+//
+// One stream, PCM arriving in host memory, frames wanted in host memory: batches of frames are kept in flight so
+// that the upload of batch k+1, the kernels of batch k and the download of batch k-1 overlap, and consecutive
+// batches go to the listed GPUs in turn (a frame depends on nothing but its own samples and its number,
+// stream_encoder.c:2866-2923, so frame ranges can be coded anywhere and handed back in order).  A batch border is
+// always the start of a loose mid/side decision period (stream_encoder.c:2958-2967), which makes a batch
+// independent of the assignment chosen before it.
+//
+// Each GPU listed ("lane") has one encoder workspace and three streams: uploads, kernels, downloads.  A slot is
+// the storage of one batch in flight: pinned host PCM, device PCM, device frames, pinned host frames and sizes.
+// The caller fills the pinned PCM of the next slot itself (no second host copy), submits it, and collects batches
+// in submission order.
+
+struct PipeMeta { uint32_t status, last_assignment; uint64_t total; };
+
+struct PipeSlot {
+	uint32_t lane;
+	void *h_pcm, *d_pcm;
+	uint8_t *d_out, *h_out; uint32_t *d_fb, *h_fb;
+	PipeMeta *h_meta;
+	hipEvent_t ev_in, ev_k, ev_done;
+	FaCfg cfg; uint64_t nsamples;
+	uint8_t *big; size_t big_cap;   // host copy of a batch holding frames beyond the usual size bound
+	int collected;
+};
+
+struct PipeLane { int device; flacamd_encoder *enc; hipStream_t hs, cs, ds; };
+
+struct flacamd_pipe {
+	flacamd_params p;
+	int pcm_format; uint32_t batch_frames, nlanes, nslots;
+	size_t pcm_bytes, out_cap;
+	PipeLane *lanes; PipeSlot *slots;
+	uint64_t head, tail;            // batches submitted / released so far; slot of batch q is q % nslots
+};
+
+extern "C" void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues);
+
+extern "C" void flacamd_pipe_destroy(flacamd_pipe *pp)
+{
+	if(!pp) return;
+	for(uint32_t i = 0; pp->slots && i < pp->nslots; i++) {
+		PipeSlot &s = pp->slots[i];
+		if(pp->lanes && pp->lanes[s.lane].enc) (void)hipSetDevice(pp->lanes[s.lane].device);
+		if(s.ev_done) { (void)hipEventSynchronize(s.ev_done); }
+		if(s.h_pcm) (void)hipHostFree(s.h_pcm);
+		if(s.h_out) (void)hipHostFree(s.h_out);
+		if(s.h_fb) (void)hipHostFree(s.h_fb);
+		if(s.h_meta) (void)hipHostFree(s.h_meta);
+		if(s.d_pcm) (void)hipFree(s.d_pcm);
+		if(s.d_out) (void)hipFree(s.d_out);
+		if(s.d_fb) (void)hipFree(s.d_fb);
+		if(s.ev_in) (void)hipEventDestroy(s.ev_in);
+		if(s.ev_k) (void)hipEventDestroy(s.ev_k);
+		if(s.ev_done) (void)hipEventDestroy(s.ev_done);
+		free(s.big);
+	}
+	for(uint32_t l = 0; pp->lanes && l < pp->nlanes; l++) {
+		PipeLane &ln = pp->lanes[l];
+		if(!ln.enc) continue;
+		(void)hipSetDevice(ln.device);
+		if(ln.cs) { (void)hipStreamSynchronize(ln.cs); (void)hipStreamDestroy(ln.cs); }
+		if(ln.hs) (void)hipStreamDestroy(ln.hs);
+		if(ln.ds) (void)hipStreamDestroy(ln.ds);
+		flacamd_encoder_destroy(ln.enc);
+	}
+	free(pp->slots); free(pp->lanes); free(pp);
+}
+
+extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth)
+{
+	if(!out || !devices || ndevices == 0 || ndevices > 64 || !params || batch_frames == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	*out = 0;
+	if(depth < 2) depth = 2;
+	if(depth > 8) depth = 8;
+	flacamd_pipe *pp = (flacamd_pipe*)calloc(1, sizeof *pp);
+	if(!pp) return FLACAMD_E_OUT_OF_MEMORY;
+	pp->p = *params;
+	int rc = flacamd_params_resolve(&pp->p);
+	if(rc != FLACAMD_OK) { free(pp); return rc; }
+	if(pp->p.channels == 2 && pp->p.do_mid_side && pp->p.loose_mid_side) {   // batch borders on decision period borders
+		unsigned lp = (unsigned)((double)pp->p.sample_rate * 0.4 / (double)pp->p.blocksize + 0.5);
+		if(lp == 0) lp = 1;
+		batch_frames = (batch_frames + lp - 1) / lp * lp;
+	}
+	pp->pcm_format = pp->p.bits_per_sample <= 16 ? FLACAMD_PCM_S16 : FLACAMD_PCM_S32;
+	pp->batch_frames = batch_frames; pp->nlanes = ndevices; pp->nslots = ndevices * depth;
+	pp->lanes = (PipeLane*)calloc(pp->nlanes, sizeof(PipeLane));
+	pp->slots = (PipeSlot*)calloc(pp->nslots, sizeof(PipeSlot));
+	if(!pp->lanes || !pp->slots) { flacamd_pipe_destroy(pp); return FLACAMD_E_OUT_OF_MEMORY; }
+	pp->pcm_bytes = (size_t)batch_frames * pp->p.blocksize * pp->p.channels * (pp->pcm_format == FLACAMD_PCM_S16 ? 2u : 4u);
+	for(uint32_t l = 0; l < pp->nlanes; l++) {
+		PipeLane &ln = pp->lanes[l];
+		ln.device = devices[l];
+		rc = flacamd_encoder_create(&ln.enc, ln.device, &pp->p, batch_frames);
+		if(rc != FLACAMD_OK) { ln.enc = 0; flacamd_pipe_destroy(pp); return rc; }
+		hipError_t he = hipStreamCreateWithFlags(&ln.hs, hipStreamNonBlocking);
+		if(he == hipSuccess) he = hipStreamCreateWithFlags(&ln.cs, hipStreamNonBlocking);
+		if(he == hipSuccess) he = hipStreamCreateWithFlags(&ln.ds, hipStreamNonBlocking);
+		if(he != hipSuccess) { rc = hip_fail(he, "hipStreamCreate(pipe)"); flacamd_pipe_destroy(pp); return rc; }
+	}
+	pp->out_cap = flacamd_encoder_max_output_bytes(pp->lanes[0].enc, batch_frames);
+	for(uint32_t i = 0; i < pp->nslots; i++) {
+		PipeSlot &s = pp->slots[i];
+		s.lane = i % pp->nlanes;
+		hipError_t he = hipSetDevice(pp->lanes[s.lane].device);
+		if(he == hipSuccess) he = hipHostMalloc(&s.h_pcm, pp->pcm_bytes, hipHostMallocPortable);
+		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_out, pp->out_cap, hipHostMallocPortable);
+		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_fb, (size_t)batch_frames * 4u, hipHostMallocPortable);
+		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_meta, sizeof(PipeMeta), hipHostMallocPortable);
+		if(he == hipSuccess) he = hipMalloc(&s.d_pcm, pp->pcm_bytes);
+		if(he == hipSuccess) he = hipMalloc((void**)&s.d_out, pp->out_cap);
+		if(he == hipSuccess) he = hipMalloc((void**)&s.d_fb, (size_t)batch_frames * 4u);
+		if(he == hipSuccess) he = hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming);
+		if(he == hipSuccess) he = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming);
+		if(he == hipSuccess) he = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
+		if(he != hipSuccess) { rc = hip_fail(he, "pipe slot allocation"); flacamd_pipe_destroy(pp); return rc; }
+	}
+	*out = pp;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_pipe_pcm_format(const flacamd_pipe *pp) { return pp ? pp->pcm_format : FLACAMD_E_INVALID_ARGUMENT; }
+extern "C" uint32_t flacamd_pipe_batch_frames(const flacamd_pipe *pp) { return pp ? pp->batch_frames : 0; }
+extern "C" uint32_t flacamd_pipe_slots(const flacamd_pipe *pp) { return pp ? pp->nslots : 0; }
+extern "C" uint32_t flacamd_pipe_in_flight(const flacamd_pipe *pp) { return pp ? (uint32_t)(pp->head - pp->tail) : 0; }
+extern "C" const flacamd_params *flacamd_pipe_params(const flacamd_pipe *pp) { return pp ? &pp->p : 0; }
+
+extern "C" size_t flacamd_pipe_max_batch_bytes(const flacamd_pipe *pp) { return pp ? pp->out_cap : 0; }
+extern "C" void *flacamd_pipe_slot_buffer(flacamd_pipe *pp, uint32_t slot) { return pp && slot < pp->nslots ? pp->slots[slot].h_pcm : 0; }
+
+extern "C" void *flacamd_pipe_fill_buffer(flacamd_pipe *pp)
+{
+	if(!pp || pp->head - pp->tail >= pp->nslots) return 0;
+	return pp->slots[pp->head % pp->nslots].h_pcm;
+}
+
+extern "C" int flacamd_pipe_submit(flacamd_pipe *pp, uint64_t nsamples, int final_block, uint32_t first_frame_number)
+{
+	if(!pp || nsamples == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pp->head - pp->tail >= pp->nslots) return FLACAMD_E_CAPACITY;
+	const uint32_t N = pp->p.blocksize;
+	const uint64_t F64 = (nsamples + N - 1) / N;
+	if(F64 > pp->batch_frames) return FLACAMD_E_CAPACITY;
+	if(!final_block && nsamples % N != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	PipeSlot &s = pp->slots[pp->head % pp->nslots];
+	PipeLane &ln = pp->lanes[s.lane];
+	flacamd_encoder *e = ln.enc;
+	HIP_TRY(hipSetDevice(ln.device));
+	FaCfg c = e->cfg;
+	c.pcm_format = (uint32_t)pp->pcm_format;
+	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
+	c.last_n = (uint32_t)(nsamples - (F64 - 1) * N);
+	c.last_fractional = (final_block && c.last_n != N) ? 1u : 0u;
+	c.first_frame = first_frame_number; c.prev_assignment = 0;
+	c.multi = 0; c.skip_full = 0;
+	s.cfg = c; s.nsamples = nsamples; s.collected = 0;
+	const size_t in_bytes = (size_t)nsamples * pp->p.channels * (pp->pcm_format == FLACAMD_PCM_S16 ? 2u : 4u);
+	HIP_TRY(hipMemcpyAsync(s.d_pcm, s.h_pcm, in_bytes, hipMemcpyHostToDevice, ln.hs));
+	HIP_TRY(hipEventRecord(s.ev_in, ln.hs));
+	HIP_TRY(hipStreamWaitEvent(ln.cs, s.ev_in, 0));
+	const int rc = enqueue_batch(e, c, s.d_pcm, s.d_out, pp->out_cap, s.d_fb, ln.cs);
+	if(rc != FLACAMD_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(&s.h_meta->status, e->work.status, 4, hipMemcpyDeviceToHost, ln.cs));
+	HIP_TRY(hipMemcpyAsync(&s.h_meta->total, e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, ln.cs));
+	HIP_TRY(hipMemcpyAsync(&s.h_meta->last_assignment, e->work.assignment + (c.F - 1), 4, hipMemcpyDeviceToHost, ln.cs));
+	HIP_TRY(hipMemcpyAsync(s.h_fb, s.d_fb, (size_t)c.F * 4u, hipMemcpyDeviceToHost, ln.cs));
+	HIP_TRY(hipEventRecord(s.ev_k, ln.cs));
+	// the frames: their total is only known on the device, so the copy takes the batch's size bound (a little more
+	// than the PCM it came from); it runs on the copy engine in the direction the uploads leave idle
+	size_t out_bytes = (size_t)c.F * c.slot_bytes;
+	if(out_bytes > pp->out_cap) out_bytes = pp->out_cap;
+	HIP_TRY(hipStreamWaitEvent(ln.ds, s.ev_k, 0));
+	HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, ln.ds));
+	HIP_TRY(hipEventRecord(s.ev_done, ln.ds));
+	pp->head++;
+	return FLACAMD_OK;
+}
+
+// 1 when the oldest batch in flight has finished (collect would not wait), 0 when not, <0 on error
+extern "C" int flacamd_pipe_ready(flacamd_pipe *pp)
+{
+	if(!pp || pp->head == pp->tail) return FLACAMD_E_INVALID_ARGUMENT;
+	PipeSlot &s = pp->slots[pp->tail % pp->nslots];
+	if(s.collected) return 1;
+	const hipError_t he = hipEventQuery(s.ev_done);
+	if(he == hipSuccess) return 1;
+	if(he == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+	return hip_fail(he, "hipEventQuery");
+}
+
+extern "C" int flacamd_pipe_collect(flacamd_pipe *pp, const uint8_t **h_frames, const uint32_t **h_frame_bytes, uint32_t *nframes,
+	uint64_t *total_bytes, const void **h_pcm, uint64_t *nsamples, uint32_t *first_frame_number)
+{
+	if(!pp || pp->head == pp->tail) return FLACAMD_E_INVALID_ARGUMENT;
+	PipeSlot &s = pp->slots[pp->tail % pp->nslots];
+	PipeLane &ln = pp->lanes[s.lane];
+	HIP_TRY(hipSetDevice(ln.device));
+	const uint8_t *frames = s.h_out;
+	if(!s.collected) {
+		HIP_TRY(hipEventSynchronize(s.ev_done));
+		if(s.h_meta->status & 1u) {
+			// a frame beyond its slot (see repack_long): this batch once more, synchronously, with the buffers it takes.  The
+			// batches submitted after it have used the workspace in stream order; wait for them before touching it again.
+			HIP_TRY(hipStreamSynchronize(ln.cs));
+			uint64_t total = 0; void *tmp = 0;
+			int rc = run_batch(ln.enc, s.cfg, s.d_pcm, s.d_out, pp->out_cap, s.d_fb, &total, ln.cs);
+			const void *src = s.d_out;
+			if(rc == FLACAMD_E_CAPACITY && total > pp->out_cap) {
+				hipError_t he = hipMalloc(&tmp, total);
+				if(he != hipSuccess) return hip_fail(he, "hipMalloc(long frames)");
+				rc = run_batch(ln.enc, s.cfg, s.d_pcm, tmp, total, s.d_fb, &total, ln.cs);
+				src = tmp;
+			}
+			if(rc == FLACAMD_OK && s.big_cap < total) { free(s.big); s.big = (uint8_t*)malloc(total); s.big_cap = s.big ? total : 0; if(!s.big) rc = FLACAMD_E_OUT_OF_MEMORY; }
+			hipError_t he = hipSuccess;
+			if(rc == FLACAMD_OK) he = hipMemcpy(s.big, src, total, hipMemcpyDeviceToHost);
+			if(rc == FLACAMD_OK && he == hipSuccess) he = hipMemcpy(s.h_fb, s.d_fb, (size_t)s.cfg.F * 4u, hipMemcpyDeviceToHost);
+			if(rc == FLACAMD_OK && he == hipSuccess) he = hipMemcpy(&s.h_meta->last_assignment, ln.enc->work.assignment + (s.cfg.F - 1), 4, hipMemcpyDeviceToHost);
+			if(tmp) (void)hipFree(tmp);
+			if(rc != FLACAMD_OK) return rc;
+			if(he != hipSuccess) return hip_fail(he, "long frames readback");
+			s.h_meta->total = total; s.h_meta->status = 4u;   // frames are in s.big
+		}
+		else if(s.h_meta->status & 2u) return FLACAMD_E_CAPACITY;
+		s.collected = 1;
+	}
+	if(s.h_meta->status & 4u) frames = s.big;
+	if(h_frames) *h_frames = frames;
+	if(h_frame_bytes) *h_frame_bytes = s.h_fb;
+	if(nframes) *nframes = s.cfg.F;
+	if(total_bytes) *total_bytes = s.h_meta->total;
+	if(h_pcm) *h_pcm = s.h_pcm;
+	if(nsamples) *nsamples = s.nsamples;
+	if(first_frame_number) *first_frame_number = s.cfg.first_frame;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_pipe_release(flacamd_pipe *pp)
+{
+	if(!pp || pp->head == pp->tail || !pp->slots[pp->tail % pp->nslots].collected) return FLACAMD_E_INVALID_ARGUMENT;
+	pp->slots[pp->tail % pp->nslots].collected = 0;
+	pp->tail++;
+	return FLACAMD_OK;
+}
+
+// int32 samples that fit 16 bits -> int16 (the upload of a 16-bit stream then moves half the bytes)
+extern "C" void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues)
+{
+	size_t i = 0;
+#if defined(__SSE2__)
+	for(; i + 16 <= nvalues; i += 16) {
+		const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 4));
+		const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 8)), d = _mm_loadu_si128((const __m128i*)(src + i + 12));
+		// 16-bit truncation, not saturation: what a cast does (shift the low halves up, arithmetic shift back, pack)
+		_mm_storeu_si128((__m128i*)(dst + i), _mm_packs_epi32(_mm_srai_epi32(_mm_slli_epi32(a, 16), 16), _mm_srai_epi32(_mm_slli_epi32(b, 16), 16)));
+		_mm_storeu_si128((__m128i*)(dst + i + 8), _mm_packs_epi32(_mm_srai_epi32(_mm_slli_epi32(c, 16), 16), _mm_srai_epi32(_mm_slli_epi32(d, 16), 16)));
+	}
+#endif
+	for(; i < nvalues; i++) dst[i] = (int16_t)src[i];
+}
+
+// A whole stream (or a run of whole blocks of one) from host memory through the pipe: the frames come out back to
+// back in h_out, one size per frame in h_frame_bytes.
+extern "C" int flacamd_pipe_encode_host(flacamd_pipe *pp, const void *h_pcm, int pcm_format, uint64_t nsamples, int final_block, uint32_t first_frame_number,
+	uint8_t *h_out, size_t out_cap, uint32_t *h_frame_bytes, size_t frame_cap, uint64_t *h_total_bytes, uint32_t *h_nframes)
+{
+	if(!pp || !h_pcm || !h_out || nsamples == 0 || pp->head != pp->tail) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && pp->pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t N = pp->p.blocksize, ch = pp->p.channels;
+	if(!final_block && nsamples % N != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint64_t batch = (uint64_t)pp->batch_frames * N;
+	uint64_t fed = 0, total = 0; size_t nf = 0; int rc = FLACAMD_OK; int short_out = 0;
+	auto drain_one = [&]() -> int {
+		const uint8_t *fr; const uint32_t *fb; uint32_t n; uint64_t tb;
+		int r = flacamd_pipe_collect(pp, &fr, &fb, &n, &tb, 0, 0, 0);
+		if(r != FLACAMD_OK) return r;
+		if(total + tb <= out_cap && nf + n <= frame_cap && !short_out) {
+			memcpy(h_out + total, fr, tb);
+			if(h_frame_bytes) memcpy(h_frame_bytes + nf, fb, (size_t)n * 4u);
+		}
+		else short_out = 1;
+		total += tb; nf += n;
+		return flacamd_pipe_release(pp);
+	};
+	while(fed < nsamples && rc == FLACAMD_OK) {
+		void *dst = flacamd_pipe_fill_buffer(pp);
+		if(!dst) { rc = drain_one(); continue; }
+		const uint64_t n = nsamples - fed < batch ? nsamples - fed : batch;
+		const size_t in_wide = (size_t)ch * (pcm_format == FLACAMD_PCM_S16 ? 2u : 4u);
+		if(pcm_format == pp->pcm_format) memcpy(dst, (const uint8_t*)h_pcm + fed * in_wide, (size_t)n * in_wide);
+		else flacamd_pcm_narrow((int16_t*)dst, (const int32_t*)h_pcm + fed * ch, (size_t)n * ch);
+		rc = flacamd_pipe_submit(pp, n, final_block && fed + n == nsamples, first_frame_number + (uint32_t)(fed / N));
+		fed += n;
+	}
+	while(pp->head != pp->tail) {
+		const int r = drain_one();
+		if(r != FLACAMD_OK) { if(rc == FLACAMD_OK) rc = r; // give the remaining slots back without their output
+			while(pp->head != pp->tail) { PipeSlot &s = pp->slots[pp->tail % pp->nslots]; (void)hipSetDevice(pp->lanes[s.lane].device); (void)hipEventSynchronize(s.ev_done); s.collected = 0; pp->tail++; } }
+	}
+	if(h_total_bytes) *h_total_bytes = total;
+	if(h_nframes) *h_nframes = (uint32_t)nf;
+	if(rc == FLACAMD_OK && short_out) rc = FLACAMD_E_CAPACITY;
+	return rc;
 }
 
 // ---- md5 entry point is implemented in k_md5.hip

@@ -9,6 +9,7 @@
 #define _FILE_OFFSET_BITS 64
 #include "../../include/flac_amd_stream.h"
 #include "../../include/flac_amd_engine.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/types.h>
@@ -39,7 +40,7 @@ struct FLAC__StreamEncoder {
 	FLAC__bool verify, streamable_subset, do_md5, do_escape_coding;
 	unsigned rice_parameter_search_dist;
 	FLAC__uint64 total_samples_estimate;
-	int device; unsigned batch_frames;
+	int devices[64]; unsigned ndevices, batch_frames, depth;   /* GPUs the batches go to in turn, frames per batch, batches in flight per GPU */
 	/* callbacks */
 	FLAC__StreamEncoderWriteCallback write_cb; FLAC__StreamEncoderSeekCallback seek_cb; FLAC__StreamEncoderTellCallback tell_cb;
 	FLAC__StreamEncoderMetadataCallback metadata_cb; FLAC__StreamEncoderProgressCallback progress_cb; void *client_data;
@@ -49,18 +50,29 @@ struct FLAC__StreamEncoder {
 	FLAC__uint64 streaminfo_offset, audio_offset, bytes_written, samples_written;
 	unsigned frames_written, total_frames_estimate, current_frame_number;
 	md5_state md5;
-	/* engine + batch queue */
-	flacamd_encoder *engine;
-	int32_t *queue; size_t queue_cap_samples, queued;   /* interleaved wide samples */
-	uint8_t *out; size_t out_cap; uint32_t *frame_bytes;
-	uint32_t last_assignment;
+	/* The batches.  Samples go straight from the client's buffer into the pinned upload buffer of the batch being
+	 * filled (as int16 for streams of at most 16 bits); full batches are in flight on the GPUs while the next one
+	 * fills, and come back in order (flacamd_pipe_*).  There is no second host copy and no CPU coding path. */
+	flacamd_pipe *pipe;
+	int fmt16;                        /* the pipe's PCM layout is int16 */
+	uint8_t *fill; size_t filled;     /* batch being filled: its buffer, wide samples in it */
+	size_t batch_samples;             /* wide samples of a full batch */
+	unsigned next_frame_number;       /* number of the first frame of the batch being filled */
+	unsigned nslots; uint8_t **slot_buf; /* the pipe's upload buffers in the order they are filled */
+	uint64_t batches_started;         /* batches whose filling has begun: batch q fills slot q % nslots */
+	size_t vdec_cap;
+	/* MD5 of the samples (md5.c:394-420) on a thread of its own: one stream is one serial chain, about 0.6 GB/s on a
+	 * host core, far below what the GPU codes; it reads the samples where the client thread put them */
+	pthread_t md5_thread; int md5_running, md5_quit;
+	pthread_mutex_t md5_lock; pthread_cond_t md5_data, md5_space;
+	uint64_t md5_produced, md5_hashed; /* wide samples written into upload buffers / hashed so far */
 	uint8_t *md5_scratch;
 	/* client metadata blocks (:1711-1741: the array is ours, the blocks are the client's) and seek table tracking (:2458-2485) */
 	FLAC__StreamMetadata **metadata; unsigned num_metadata;
 	FLAC__StreamMetadata_SeekTable *seek_table; unsigned first_seekpoint_to_check;
 	FLAC__uint64 seektable_offset;
 	/* verify mode (:984-1017): device decoder, its output, what the reference keeps in verify.error_stats */
-	flacamd_decoder *vdec; int32_t *vpcm;
+	flacamd_decoder *vdec; void *vpcm;
 	FLAC__StreamDecoderState vstate;
 	struct verify_stats { FLAC__uint64 absolute_sample; unsigned frame_number, channel, sample; FLAC__int32 expected, got; } vstats;
 	struct { int armed; FLAC__uint64 absolute_sample; unsigned channel; FLAC__int32 mask; } sample_fault;
@@ -69,12 +81,13 @@ struct FLAC__StreamEncoder {
 
 static void set_defaults(FLAC__StreamEncoder *e) /* set_defaults_, :2107-2160 */
 {
-	const int device = e->device; const unsigned batch = e->batch_frames;
+	int devices[64]; const unsigned ndev = e->ndevices, batch = e->batch_frames, depth = e->depth;
 	const struct verify_stats keep = e->vstats; /* the reference only clears these at init (:1012-1017) */
+	memcpy(devices, e->devices, sizeof devices);
 	free(e->metadata);
 	memset(e, 0, sizeof *e);
 	e->vstats = keep; e->vstate = FLAC__STREAM_DECODER_UNINITIALIZED; /* what the finished verify decoder reports (:1351) */
-	e->device = device; e->batch_frames = batch ? batch : 1024u;
+	memcpy(e->devices, devices, sizeof devices); e->ndevices = ndev ? ndev : 1u; e->batch_frames = batch ? batch : 1024u; e->depth = depth;
 	e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
 	e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1;
 	e->p.channels = 2; e->p.bits_per_sample = 16; e->p.sample_rate = 44100; e->p.blocksize = 0;
@@ -88,12 +101,17 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 	return e;
 }
 
+static void md5_stop(FLAC__StreamEncoder *e);
+static void *md5_worker(void *arg);
+
 static void free_buffers(FLAC__StreamEncoder *e)
 {
-	if(e->engine) { flacamd_encoder_destroy(e->engine); e->engine = 0; }
+	md5_stop(e);
+	if(e->pipe) { flacamd_pipe_destroy(e->pipe); e->pipe = 0; }
 	if(e->vdec) { flacamd_decoder_destroy(e->vdec); e->vdec = 0; }
 	free(e->vpcm); e->vpcm = 0;
-	free(e->queue); e->queue = 0; free(e->out); e->out = 0; free(e->frame_bytes); e->frame_bytes = 0; free(e->md5_scratch); e->md5_scratch = 0;
+	free(e->slot_buf); e->slot_buf = 0; free(e->md5_scratch); e->md5_scratch = 0;
+	e->fill = 0; e->filled = 0;
 }
 
 void FLAC__stream_encoder_delete(FLAC__StreamEncoder *e)
@@ -168,12 +186,25 @@ FLAC__bool flacamd_stream_encoder_inject_frame_fault(FLAC__StreamEncoder *e, uns
 FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *e, int device)
 {
 	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || device < 0) return 0;
-	e->device = device; return 1;
+	e->devices[0] = device; e->ndevices = 1; return 1;
+}
+FLAC__bool flacamd_stream_encoder_set_devices(FLAC__StreamEncoder *e, unsigned num_devices, const int *device_ids)
+{
+	unsigned i;
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || num_devices == 0 || num_devices > 64 || !device_ids) return 0;
+	for(i = 0; i < num_devices; i++) if(device_ids[i] < 0) return 0;
+	memcpy(e->devices, device_ids, sizeof(int) * num_devices); e->ndevices = num_devices;
+	return 1;
 }
 FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *e, unsigned frames)
 {
 	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || frames == 0) return 0;
 	e->batch_frames = frames; return 1;
+}
+FLAC__bool flacamd_stream_encoder_set_batches_in_flight(FLAC__StreamEncoder *e, unsigned per_device)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || per_device < 2 || per_device > 8) return 0;
+	e->depth = per_device; return 1;
 }
 
 /* :1531-1600: ';'-separated window names, tukey(p) / gauss(stddev) take a parameter,
@@ -383,24 +414,35 @@ static FLAC__StreamEncoderInitStatus init_internal(FLAC__StreamEncoder *e, FLAC_
 
 	e->state = FLAC__STREAM_ENCODER_OK;
 	e->write_cb = wcb; e->seek_cb = scb; e->tell_cb = tcb; e->metadata_cb = mcb; e->client_data = client_data;
-	e->current_frame_number = 0; e->queued = 0; e->last_assignment = 0;
+	e->current_frame_number = 0;
 	e->streaminfo_offset = 0; e->audio_offset = 0;
 
-	rc = flacamd_encoder_create(&e->engine, e->device, p, e->batch_frames);
+	e->next_frame_number = 0; e->batches_started = 0; e->filled = 0; e->fill = 0;
+	rc = flacamd_pipe_create(&e->pipe, e->devices, e->ndevices, p, e->batch_frames, e->depth ? e->depth : (e->ndevices > 1 ? 2u : 3u));
 	if(rc != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
-	e->queue_cap_samples = (size_t)e->batch_frames * p->blocksize + p->blocksize; /* one spare block: a batch goes out only once a later sample is known */
-	e->queue = (int32_t*)malloc(sizeof(int32_t) * e->queue_cap_samples * p->channels);
-	e->out_cap = flacamd_encoder_max_output_bytes(e->engine, e->batch_frames);
-	e->out = (uint8_t*)malloc(e->out_cap);
-	e->frame_bytes = (uint32_t*)malloc(sizeof(uint32_t) * e->batch_frames);
+	e->fmt16 = flacamd_pipe_pcm_format(e->pipe) == FLACAMD_PCM_S16;
+	e->batch_samples = (size_t)flacamd_pipe_batch_frames(e->pipe) * p->blocksize; /* the pipe rounds batches up to whole loose mid/side periods */
+	e->nslots = flacamd_pipe_slots(e->pipe);
+	e->slot_buf = (uint8_t**)calloc(e->nslots, sizeof(uint8_t*));
 	e->md5_scratch = (uint8_t*)malloc((size_t)65536 * 4);
-	if(!e->queue || !e->out || !e->frame_bytes || !e->md5_scratch) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	if(!e->slot_buf || !e->md5_scratch) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	{ unsigned i; for(i = 0; i < e->nslots; i++) e->slot_buf[i] = (uint8_t*)flacamd_pipe_slot_buffer(e->pipe, i); }
 	memset(&e->vstats, 0, sizeof e->vstats); /* :1012-1017 */
 	if(e->verify) { /* :984-1011: a decoder of our own; sized for a whole batch plus false sync candidates */
-		rc = flacamd_decoder_create(&e->vdec, e->device, p->channels, p->bits_per_sample, p->blocksize, 2 * e->batch_frames + 256, e->out_cap);
-		e->vpcm = (int32_t*)malloc(sizeof(int32_t) * (size_t)e->batch_frames * p->blocksize * p->channels);
+		const unsigned bf = flacamd_pipe_batch_frames(e->pipe);
+		e->vdec_cap = flacamd_pipe_max_batch_bytes(e->pipe);
+		rc = flacamd_decoder_create(&e->vdec, e->devices[0], p->channels, p->bits_per_sample, p->blocksize, 2 * bf + 256, e->vdec_cap);
+		e->vpcm = malloc((e->fmt16 ? sizeof(int16_t) : sizeof(int32_t)) * (size_t)bf * p->blocksize * p->channels);
 		if(rc != FLACAMD_OK || !e->vpcm) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
 		e->vstate = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
+	}
+	if(e->do_md5) {
+		md5_init(&e->md5);
+		e->md5_produced = e->md5_hashed = 0; e->md5_quit = 0;
+		if(pthread_mutex_init(&e->md5_lock, 0) || pthread_cond_init(&e->md5_data, 0) || pthread_cond_init(&e->md5_space, 0) || pthread_create(&e->md5_thread, 0, md5_worker, e)) {
+			e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+		}
+		e->md5_running = 1;
 	}
 
 	/* stream head: "fLaC", STREAMINFO, empty VORBIS_COMMENT carrying the vendor string (:1034-1106,
@@ -469,90 +511,93 @@ FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder
 	return FLAC__stream_encoder_init_FILE(e, f, pcb, client_data);
 }
 
-/* first difference between decoded and queued samples of one frame, searched channel by channel like
- * verify_write_callback_ (:4207-4231) */
-static int frame_differs(FLAC__StreamEncoder *e, const int32_t *got, const int32_t *expected, unsigned blocksize, FLAC__uint64 first_sample)
+/* sample i (interleaved index) of a batch's PCM, which is int16 or int32 */
+static int32_t pcm_at(const FLAC__StreamEncoder *e, const void *pcm, size_t i) { return e->fmt16 ? (int32_t)((const int16_t*)pcm)[i] : ((const int32_t*)pcm)[i]; }
+
+/* first difference between decoded and submitted samples of one frame, searched channel by channel like
+ * verify_write_callback_ (:4207-4231); `at` = interleaved index of the frame's first sample in both buffers */
+static int frame_differs(FLAC__StreamEncoder *e, const void *got, size_t got_at, const void *expected, size_t exp_at, unsigned blocksize, FLAC__uint64 first_sample)
 {
-	const unsigned ch = e->p.channels; unsigned c, i;
-	if(0 == memcmp(got, expected, sizeof(int32_t) * (size_t)blocksize * ch)) return 0;
-	for(c = 0; c < ch; c++) for(i = 0; i < blocksize; i++) if(got[(size_t)i * ch + c] != expected[(size_t)i * ch + c]) {
-		e->vstats.absolute_sample = first_sample + i; e->vstats.frame_number = (unsigned)(first_sample / blocksize);
-		e->vstats.channel = c; e->vstats.sample = i; e->vstats.expected = expected[(size_t)i * ch + c]; e->vstats.got = got[(size_t)i * ch + c];
-		return 1;
+	const unsigned ch = e->p.channels; unsigned c, i; const size_t w = e->fmt16 ? 2u : 4u;
+	if(0 == memcmp((const uint8_t*)got + got_at * w, (const uint8_t*)expected + exp_at * w, w * (size_t)blocksize * ch)) return 0;
+	for(c = 0; c < ch; c++) for(i = 0; i < blocksize; i++) {
+		const int32_t g = pcm_at(e, got, got_at + (size_t)i * ch + c), x = pcm_at(e, expected, exp_at + (size_t)i * ch + c);
+		if(g != x) {
+			e->vstats.absolute_sample = first_sample + i; e->vstats.frame_number = (unsigned)(first_sample / blocksize); /* the frame's own length, as the reference divides (:4214) */
+			e->vstats.channel = c; e->vstats.sample = i; e->vstats.expected = x; e->vstats.got = g;
+			return 1;
+		}
 	}
 	return 0;
 }
 
-/* Decode the batch just coded on the device and compare with the queue.  Returns the number of leading
- * frames that verified; when that is less than nframes, *bad is the encoder state the failing frame asks for. */
-static unsigned verify_batch(FLAC__StreamEncoder *e, size_t nsamples, unsigned nframes, size_t total_bytes, FLAC__StreamEncoderState *bad)
+/* Decode the batch just coded on the device and compare with the samples it was made from.  Returns the number of
+ * leading frames that verified; when that is less than nframes, *bad is the encoder state the failing frame asks for. */
+static unsigned verify_batch(FLAC__StreamEncoder *e, uint8_t *frames, const uint32_t *frame_bytes, void *pcm, size_t nsamples, unsigned nframes, size_t total_bytes, unsigned first_frame, FLAC__StreamEncoderState *bad)
 {
 	const unsigned N = e->p.blocksize, ch = e->p.channels;
-	const FLAC__uint64 batch_first = (FLAC__uint64)e->current_frame_number * N;
+	const int fmt = e->fmt16 ? FLACAMD_PCM_S16 : FLACAMD_PCM_S32;
+	const FLAC__uint64 batch_first = (FLAC__uint64)first_frame * N;
 	uint64_t info[4] = { 0, 0, 0, 0 };
 	unsigned f; size_t off = 0; int rc;
-	if(e->frame_fault.armed && e->frame_fault.frame_number >= e->current_frame_number && e->frame_fault.frame_number < e->current_frame_number + nframes) {
-		size_t o = 0; const unsigned rel = e->frame_fault.frame_number - e->current_frame_number;
-		for(f = 0; f < rel; f++) o += e->frame_bytes[f];
-		if(e->frame_fault.byte_index < e->frame_bytes[rel]) e->out[o + e->frame_fault.byte_index] ^= (uint8_t)e->frame_fault.mask;
+	if(total_bytes > e->vdec_cap) { /* frames beyond the usual bound: the verify decoder takes a batch of that size too */
+		flacamd_decoder_destroy(e->vdec); e->vdec = 0; e->vdec_cap = total_bytes;
+		if(flacamd_decoder_create(&e->vdec, e->devices[0], ch, e->p.bits_per_sample, N, 2 * flacamd_pipe_batch_frames(e->pipe) + 256, e->vdec_cap) != FLACAMD_OK) {
+			*bad = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0;
+		}
+	}
+	if(e->frame_fault.armed && e->frame_fault.frame_number >= first_frame && e->frame_fault.frame_number < first_frame + nframes) {
+		size_t o = 0; const unsigned rel = e->frame_fault.frame_number - first_frame;
+		for(f = 0; f < rel; f++) o += frame_bytes[f];
+		if(e->frame_fault.byte_index < frame_bytes[rel]) frames[o + e->frame_fault.byte_index] ^= (uint8_t)e->frame_fault.mask;
 		e->frame_fault.armed = 0;
 	}
 	if(e->sample_fault.armed && e->sample_fault.absolute_sample >= batch_first && e->sample_fault.absolute_sample < batch_first + nsamples && e->sample_fault.channel < ch) {
-		e->queue[(size_t)(e->sample_fault.absolute_sample - batch_first) * ch + e->sample_fault.channel] ^= e->sample_fault.mask;
+		const size_t i = (size_t)(e->sample_fault.absolute_sample - batch_first) * ch + e->sample_fault.channel;
+		if(e->fmt16) ((int16_t*)pcm)[i] ^= (int16_t)e->sample_fault.mask; else ((int32_t*)pcm)[i] ^= e->sample_fault.mask;
 		e->sample_fault.armed = 0;
 	}
-	rc = flacamd_decode_host(e->vdec, e->out, total_bytes, e->vpcm, FLACAMD_PCM_S32, nsamples, info);
+	rc = flacamd_decode_host(e->vdec, frames, total_bytes, e->vpcm, fmt, nsamples, info);
 	if(rc == FLACAMD_OK && info[0] == nframes && info[1] == nsamples && info[3] == total_bytes) {
-		if(0 == memcmp(e->vpcm, e->queue, sizeof(int32_t) * nsamples * ch)) return nframes;
+		if(0 == memcmp(e->vpcm, pcm, (e->fmt16 ? 2u : 4u) * nsamples * ch)) return nframes;
 		for(f = 0; f < nframes; f++) {
 			const unsigned bs = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
-			if(frame_differs(e, e->vpcm + (size_t)f * N * ch, e->queue + (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
+			if(frame_differs(e, e->vpcm, (size_t)f * N * ch, pcm, (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
 		}
 		return nframes;
 	}
 	/* the batch did not decode as a whole: find the frame, one at a time */
 	for(f = 0; f < nframes; f++) {
 		const unsigned bs = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
-		rc = flacamd_decode_host(e->vdec, e->out + off, e->frame_bytes[f], e->vpcm, FLACAMD_PCM_S32, bs, info);
-		if(rc != FLACAMD_OK || info[0] != 1 || info[1] != bs || info[3] != e->frame_bytes[f]) {
+		rc = flacamd_decode_host(e->vdec, frames + off, frame_bytes[f], e->vpcm, fmt, bs, info);
+		if(rc != FLACAMD_OK || info[0] != 1 || info[1] != bs || info[3] != frame_bytes[f]) {
 			/* what verify_error_callback_ leaves behind (:4245-4250); the reference's decoder would be hunting for the next sync */
 			*bad = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; e->vstate = (rc == FLACAMD_OK || rc == FLACAMD_E_BAD_STREAM) ? FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC : FLAC__STREAM_DECODER_ABORTED;
 			return f;
 		}
-		if(frame_differs(e, e->vpcm, e->queue + (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
-		off += e->frame_bytes[f];
+		if(frame_differs(e, e->vpcm, 0, pcm, (size_t)f * N * ch, bs, batch_first + (FLAC__uint64)f * N)) { *bad = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA; return f; }
+		off += frame_bytes[f];
 	}
 	*bad = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR; e->vstate = FLAC__STREAM_DECODER_ABORTED; /* every frame decodes alone but the batch does not */
 	return 0;
 }
 
-/* Code `nsamples` queued wide samples on the engine and replay the per-frame writes. */
-static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final_block)
+/* Take the oldest batch in flight back from the GPU (waiting for it if need be) and replay the per-frame writes
+ * of write_bitbuffer_ / write_frame_ (:2384-2518) in stream order. */
+static FLAC__bool drain_one(FLAC__StreamEncoder *e)
 {
-	uint64_t total = 0; uint32_t last = 0; size_t off = 0; unsigned f;
-	const unsigned N = e->p.blocksize, nframes = (unsigned)((nsamples + N - 1) / N);
-	int rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
-		e->out, e->out_cap, e->frame_bytes, &total, &last);
-	if(rc == FLACAMD_E_CAPACITY && total > e->out_cap) { /* frames beyond the usual bound (a subframe whose estimate wrapped): a buffer of the size the engine names */
-		uint8_t *nb = (uint8_t*)realloc(e->out, (size_t)total);
-		if(!nb) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
-		e->out = nb; e->out_cap = (size_t)total;
-		if(e->vdec) { /* the verify decoder takes a batch of that size too */
-			flacamd_decoder_destroy(e->vdec); e->vdec = 0;
-			if(flacamd_decoder_create(&e->vdec, e->device, e->p.channels, e->p.bits_per_sample, e->p.blocksize, 2 * e->batch_frames + 256, e->out_cap) != FLACAMD_OK) { e->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR; return 0; }
-		}
-		rc = flacamd_encode_host(e->engine, e->queue, FLACAMD_PCM_S32, nsamples, final_block, e->current_frame_number, e->last_assignment,
-			e->out, e->out_cap, e->frame_bytes, &total, &last);
-	}
+	const uint8_t *frames = 0; const uint32_t *frame_bytes = 0; const void *pcm = 0;
+	uint32_t nframes = 0, first = 0; uint64_t total = 0, nsamples = 0; size_t off = 0; unsigned f;
+	const unsigned N = e->p.blocksize;
+	const int rc = flacamd_pipe_collect(e->pipe, &frames, &frame_bytes, &nframes, &total, &pcm, &nsamples, &first);
 	if(rc != FLACAMD_OK) { e->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR; return 0; }
-	e->last_assignment = last;
 	if(e->verify) { /* write_bitbuffer_ verifies a frame before it is written (:2396-2411): stop ahead of the first bad one */
 		FLAC__StreamEncoderState bad = FLAC__STREAM_ENCODER_OK;
-		const unsigned good = verify_batch(e, nsamples, nframes, (size_t)total, &bad);
+		const unsigned good = verify_batch(e, (uint8_t*)frames, frame_bytes, (void*)pcm, (size_t)nsamples, nframes, (size_t)total, first, &bad);
 		if(good < nframes) {
 			for(f = 0; f < good; f++) {
-				if(!emit(e, e->out + off, e->frame_bytes[f], N)) return 0;
-				off += e->frame_bytes[f]; e->current_frame_number++; e->streaminfo.data.stream_info.total_samples += N;
+				if(!emit(e, frames + off, frame_bytes[f], N)) return 0;
+				off += frame_bytes[f]; e->current_frame_number++; e->streaminfo.data.stream_info.total_samples += N;
 			}
 			e->state = bad;
 			return 0;
@@ -560,45 +605,120 @@ static FLAC__bool flush_batch(FLAC__StreamEncoder *e, size_t nsamples, int final
 	}
 	for(f = 0; f < nframes; f++) {
 		const unsigned samples = (f + 1 == nframes) ? (unsigned)(nsamples - (size_t)f * N) : N;
-		if(!emit(e, e->out + off, e->frame_bytes[f], samples)) return 0;
-		off += e->frame_bytes[f];
+		if(!emit(e, frames + off, frame_bytes[f], samples)) return 0;
+		off += frame_bytes[f];
 		e->current_frame_number++;
 		e->streaminfo.data.stream_info.total_samples += samples; /* :2920 */
 	}
+	(void)flacamd_pipe_release(e->pipe);
 	return 1;
 }
 
-static void md5_feed(FLAC__StreamEncoder *e, const int32_t *interleaved, size_t nvalues)
+/* ---- MD5 worker: hashes the samples in the order they were handed over, out of the upload buffers */
+static void *md5_worker(void *arg)
 {
-	md5_feed_pcm(&e->md5, interleaved, nvalues, e->p.bits_per_sample, e->md5_scratch, (size_t)65536 * 4);
-}
-
-/* queue `n` wide samples already interleaved at the queue tail, then flush whole batches.
- * The reference codes a block once blocksize+1 samples are known (:2006, :2062), so a batch
- * only goes out when at least one later sample has arrived. */
-static FLAC__bool after_append(FLAC__StreamEncoder *e)
-{
-	const size_t batch = (size_t)e->batch_frames * e->p.blocksize;
-	while(e->queued > batch) {
-		const size_t rest = e->queued - batch;
-		if(!flush_batch(e, batch, 0)) return 0;
-		memmove(e->queue, e->queue + batch * e->p.channels, sizeof(int32_t) * rest * e->p.channels);
-		e->queued = rest;
+	FLAC__StreamEncoder *e = (FLAC__StreamEncoder*)arg;
+	const size_t ch = e->p.channels, wbytes = e->fmt16 ? 2u : 4u;
+	pthread_mutex_lock(&e->md5_lock);
+	for(;;) {
+		uint64_t from, to;
+		while(e->md5_hashed == e->md5_produced && !e->md5_quit) pthread_cond_wait(&e->md5_data, &e->md5_lock);
+		if(e->md5_hashed == e->md5_produced) break;
+		from = e->md5_hashed; to = e->md5_produced;
+		pthread_mutex_unlock(&e->md5_lock);
+		while(from < to) {
+			const uint64_t q = from / e->batch_samples; const size_t at = (size_t)(from % e->batch_samples);
+			size_t n = (size_t)(to - from);
+			const uint8_t *src = e->slot_buf[q % e->nslots] + at * ch * wbytes;
+			if(n > e->batch_samples - at) n = e->batch_samples - at;
+			if(n > (1u << 18)) n = 1u << 18; /* report progress often enough for the filling thread to get its buffer back */
+			if(e->fmt16) md5_feed_pcm16(&e->md5, (const int16_t*)src, n * ch, e->p.bits_per_sample, e->md5_scratch, (size_t)65536 * 4);
+			else md5_feed_pcm(&e->md5, (const int32_t*)src, n * ch, e->p.bits_per_sample, e->md5_scratch, (size_t)65536 * 4);
+			from += n;
+			pthread_mutex_lock(&e->md5_lock);
+			e->md5_hashed = from;
+			pthread_cond_broadcast(&e->md5_space);
+			pthread_mutex_unlock(&e->md5_lock);
+		}
+		pthread_mutex_lock(&e->md5_lock);
 	}
+	pthread_mutex_unlock(&e->md5_lock);
+	return 0;
+}
+
+/* let the worker finish what was handed over, then end it */
+static void md5_stop(FLAC__StreamEncoder *e)
+{
+	if(!e->md5_running) return;
+	pthread_mutex_lock(&e->md5_lock);
+	e->md5_quit = 1;
+	pthread_cond_broadcast(&e->md5_data);
+	pthread_mutex_unlock(&e->md5_lock);
+	pthread_join(e->md5_thread, 0);
+	pthread_mutex_destroy(&e->md5_lock); pthread_cond_destroy(&e->md5_data); pthread_cond_destroy(&e->md5_space);
+	e->md5_running = 0;
+}
+
+static void md5_publish(FLAC__StreamEncoder *e, size_t nsamples)
+{
+	if(!e->md5_running) return;
+	pthread_mutex_lock(&e->md5_lock);
+	e->md5_produced += nsamples;
+	pthread_cond_signal(&e->md5_data);
+	pthread_mutex_unlock(&e->md5_lock);
+}
+
+/* The buffer of the next batch to fill.  All batches may be in flight: then the oldest is taken back first (its
+ * frames are written out); and the MD5 worker must be done with the batch that used this buffer last. */
+static FLAC__bool begin_batch(FLAC__StreamEncoder *e)
+{
+	while((e->fill = (uint8_t*)flacamd_pipe_fill_buffer(e->pipe)) == 0) if(!drain_one(e)) return 0;
+	e->filled = 0;
+	if(e->md5_running && e->batches_started >= e->nslots) {
+		const uint64_t need = (e->batches_started - e->nslots + 1) * (uint64_t)e->batch_samples;
+		pthread_mutex_lock(&e->md5_lock);
+		while(e->md5_hashed < need) pthread_cond_wait(&e->md5_space, &e->md5_lock);
+		pthread_mutex_unlock(&e->md5_lock);
+	}
+	e->batches_started++;
 	return 1;
+}
+
+/* hand the batch being filled to the GPUs; batches that have come back meanwhile are written out */
+static FLAC__bool submit_batch(FLAC__StreamEncoder *e, int final_block)
+{
+	const unsigned N = e->p.blocksize;
+	const int rc = flacamd_pipe_submit(e->pipe, e->filled, final_block, e->next_frame_number);
+	if(rc != FLACAMD_OK) { e->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR; return 0; }
+	e->next_frame_number += (unsigned)((e->filled + N - 1) / N);
+	e->fill = 0; e->filled = 0;
+	/* with verify on, a bad frame is reported by the call that completes its block, as in the reference (:2396-2411): no batch stays in flight */
+	while(flacamd_pipe_in_flight(e->pipe) > 0 && (e->verify || flacamd_pipe_ready(e->pipe) == 1)) if(!drain_one(e)) return 0;
+	return 1;
+}
+
+/* Room for samples in the batch being filled.  The reference codes a block once blocksize+1 samples are known
+ * (:2006, :2062): a full batch is only submitted when a later sample has arrived, so that finish() can still
+ * code its last block as the final one.  Returns the number of wide samples that fit (at least 1), 0 on error. */
+static size_t room(FLAC__StreamEncoder *e)
+{
+	if(e->fill && e->filled == e->batch_samples) { if(!submit_batch(e, 0)) return 0; }
+	if(!e->fill && !begin_batch(e)) return 0;
+	return e->batch_samples - e->filled;
 }
 
 FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, const FLAC__int32 buffer[], unsigned samples)
 {
-	size_t done = 0;
+	size_t done = 0; const unsigned ch = e ? e->p.channels : 0;
 	if(!e || e->state != FLAC__STREAM_ENCODER_OK) return 0;
-	if(e->do_md5) md5_feed(e, buffer, (size_t)samples * e->p.channels);
 	while(done < samples) {
-		size_t n = e->queue_cap_samples - e->queued;
+		size_t n = room(e);
+		if(n == 0) return 0;
 		if(n > samples - done) n = samples - done;
-		memcpy(e->queue + e->queued * e->p.channels, buffer + done * e->p.channels, sizeof(int32_t) * n * e->p.channels);
-		e->queued += n; done += n;
-		if(!after_append(e)) return 0;
+		if(e->fmt16) flacamd_pcm_narrow((int16_t*)e->fill + e->filled * ch, buffer + done * ch, n * ch);
+		else memcpy((int32_t*)e->fill + e->filled * ch, buffer + done * ch, sizeof(int32_t) * n * ch);
+		e->filled += n; done += n;
+		md5_publish(e, n);
 	}
 	return 1;
 }
@@ -608,13 +728,20 @@ FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int3
 	size_t done = 0; const unsigned ch = e ? e->p.channels : 0;
 	if(!e || e->state != FLAC__STREAM_ENCODER_OK) return 0;
 	while(done < samples) {
-		size_t n = e->queue_cap_samples - e->queued, i; unsigned c;
-		int32_t *dst = e->queue + e->queued * ch;
+		size_t n = room(e), i; unsigned c;
+		if(n == 0) return 0;
 		if(n > samples - done) n = samples - done;
-		for(i = 0; i < n; i++) for(c = 0; c < ch; c++) dst[i * ch + c] = buffer[c][done + i];
-		if(e->do_md5) md5_feed(e, dst, n * ch);
-		e->queued += n; done += n;
-		if(!after_append(e)) return 0;
+		if(e->fmt16) {
+			int16_t *dst = (int16_t*)e->fill + e->filled * ch;
+			if(ch == 2) { const FLAC__int32 *l = buffer[0] + done, *r = buffer[1] + done; for(i = 0; i < n; i++) { dst[2 * i] = (int16_t)l[i]; dst[2 * i + 1] = (int16_t)r[i]; } }
+			else for(c = 0; c < ch; c++) { const FLAC__int32 *src = buffer[c] + done; for(i = 0; i < n; i++) dst[i * ch + c] = (int16_t)src[i]; }
+		}
+		else {
+			int32_t *dst = (int32_t*)e->fill + e->filled * ch;
+			for(c = 0; c < ch; c++) { const FLAC__int32 *src = buffer[c] + done; for(i = 0; i < n; i++) dst[i * ch + c] = src[i]; }
+		}
+		e->filled += n; done += n;
+		md5_publish(e, n);
 	}
 	return 1;
 }
@@ -624,8 +751,9 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e) /* :1310-1377 */
 	FLAC__bool error = 0;
 	if(!e) return 0;
 	if(e->state == FLAC__STREAM_ENCODER_UNINITIALIZED) return 1;
-	if(e->state == FLAC__STREAM_ENCODER_OK && e->queued > 0) { if(!flush_batch(e, e->queued, 1)) error = 1; e->queued = 0; }
-	if(e->do_md5) md5_final(&e->md5, e->streaminfo.data.stream_info.md5sum);
+	if(e->state == FLAC__STREAM_ENCODER_OK && e->fill && e->filled > 0) { if(!submit_batch(e, 1)) error = 1; }
+	while(e->state == FLAC__STREAM_ENCODER_OK && e->pipe && flacamd_pipe_in_flight(e->pipe) > 0) if(!drain_one(e)) error = 1;
+	if(e->do_md5 && e->md5_running) { md5_stop(e); md5_final(&e->md5, e->streaminfo.data.stream_info.md5sum); }
 	if(e->state == FLAC__STREAM_ENCODER_OK) {
 		if(e->seek_cb) { /* update_metadata_ (:2521-2620): MD5, total samples, min/max frame size patched in place */
 			const FLAC__StreamMetadata_StreamInfo *si = &e->streaminfo.data.stream_info;

@@ -78,6 +78,16 @@ def lib():
         L.flacamd_md5_device.argtypes = [C.c_int, vp, C.c_int, u32, u32, vp, u32, vp, vp]
         L.flacamd_md5_device_static.argtypes = [C.c_int, vp, C.c_int, u32, u32, vp, u32, vp, vp]
         L.flacamd_md5_device_static_max_streams.restype = u32
+        L.flacamd_pipe_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), u32, C.POINTER(Params), u32, u32]
+        L.flacamd_pipe_destroy.argtypes = [vp]
+        L.flacamd_pipe_destroy.restype = None
+        L.flacamd_pipe_batch_frames.argtypes = [vp]
+        L.flacamd_pipe_batch_frames.restype = u32
+        L.flacamd_pipe_max_batch_bytes.argtypes = [vp]
+        L.flacamd_pipe_max_batch_bytes.restype = sz
+        L.flacamd_pipe_params.argtypes = [vp]
+        L.flacamd_pipe_params.restype = C.POINTER(Params)
+        L.flacamd_pipe_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, vp, sz, vp, sz, C.POINTER(u64), C.POINTER(u32)]
         L.flacamd_decoder_create.argtypes = [C.POINTER(vp), C.c_int, u32, u32, u32, u32, sz]
         L.flacamd_decoder_destroy.argtypes = [vp]
         L.flacamd_decoder_destroy.restype = None
@@ -222,6 +232,52 @@ class Encoder:
         if got < 0:
             raise EngineError(got, "flacamd_encoder_debug_read")
         return buf[: got // buf.itemsize]
+
+
+class Pipe:
+    """One stream coded from host memory in batches kept in flight over one or several GPUs (flacamd_pipe)."""
+
+    def __init__(self, params, batch_frames, devices=(0,), depth=2):
+        self._h = C.c_void_p()
+        self._lib = lib()
+        ids = (C.c_int * len(devices))(*devices)
+        _check(self._lib.flacamd_pipe_create(C.byref(self._h), ids, len(devices), C.byref(params), batch_frames, depth), "flacamd_pipe_create")
+        self.params = self._lib.flacamd_pipe_params(self._h).contents
+        self.blocksize = int(self.params.blocksize)
+        self.channels = int(self.params.channels)
+        self.batch_frames = int(self._lib.flacamd_pipe_batch_frames(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.flacamd_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode_host(self, pcm, final=True, first_frame=0, out=None):
+        """pcm: numpy (samples, channels) int16 or int32 in ordinary host memory.  Returns (frame bytes as one
+        uint8 array, sizes) - the frames back to back."""
+        pcm = np.ascontiguousarray(pcm)
+        fmt = PCM_S16 if pcm.dtype == np.int16 else PCM_S32
+        n = pcm.shape[0]
+        F = (n + self.blocksize - 1) // self.blocksize
+        nb = (F + self.batch_frames - 1) // self.batch_frames
+        cap = nb * int(self._lib.flacamd_pipe_max_batch_bytes(self._h)) if out is None else out.nbytes
+        if out is None:
+            out = np.empty(cap, dtype=np.uint8)
+        fb = np.zeros(F, dtype=np.uint32)
+        total, nf = C.c_uint64(0), C.c_uint32(0)
+        rc = self._lib.flacamd_pipe_encode_host(self._h, pcm.ctypes.data, fmt, n, 1 if final else 0, first_frame, out.ctypes.data, cap,
+                                                fb.ctypes.data, F, C.byref(total), C.byref(nf))
+        if rc == -6 and total.value > cap:
+            raise OutputTooSmall(int(total.value))
+        _check(rc, "flacamd_pipe_encode_host")
+        assert nf.value == F
+        return out[:total.value], fb
 
 
 def device_count():

@@ -218,6 +218,8 @@ def _lib():
         L.FLAC__stream_encoder_finish.argtypes = [vp]
         L.flacamd_stream_encoder_set_device.argtypes = [vp, C.c_int]
         L.flacamd_stream_encoder_set_batch_frames.argtypes = [vp, C.c_uint]
+        L.flacamd_stream_encoder_set_batches_in_flight.argtypes = [vp, C.c_uint]
+        L.flacamd_stream_encoder_set_devices.argtypes = [vp, C.c_uint, C.POINTER(C.c_int)]
         L.FLAC__stream_encoder_get_verify_decoder_state.argtypes = [vp]
         L.FLAC__stream_encoder_get_verify_decoder_state.restype = C.c_int
         L.FLAC__stream_encoder_get_verify_decoder_error_stats.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(C.c_uint)] * 3 + [C.POINTER(C.c_int32)] * 2
@@ -255,7 +257,7 @@ class StreamEncoder:
     def __getattr__(self, name):
         # set_xxx / get_xxx / disable_xxx forward to the C functions of the same name
         if name.startswith(("set_", "get_", "disable_")):
-            fn = getattr(self._lib, ("FLAC__stream_encoder_" if not name.endswith(("set_device", "set_batch_frames")) else "flacamd_stream_encoder_") + name)
+            fn = getattr(self._lib, ("FLAC__stream_encoder_" if not name.endswith(("set_device", "set_batch_frames", "set_batches_in_flight")) else "flacamd_stream_encoder_") + name)
             if name.startswith("get_"):
                 return lambda: fn(self._h)
             if name == "set_apodization":
@@ -265,6 +267,11 @@ class StreamEncoder:
 
     def get_resolved_state_string(self):
         return self._lib.FLAC__stream_encoder_get_resolved_state_string(self._h).decode()
+
+    def set_devices(self, ids):
+        """Batches go to these HIP devices in turn (flacamd_stream_encoder_set_devices)."""
+        arr = (C.c_int * len(ids))(*ids)
+        return bool(self._lib.flacamd_stream_encoder_set_devices(self._h, len(ids), arr))
 
     def set_metadata(self, blocks):
         """blocks: list of StreamMetadata (see padding_block() etc.); they are kept alive by this object"""

@@ -137,6 +137,42 @@ int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, u
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
 	uint8_t *h_out, size_t out_cap, uint32_t *h_frame_bytes, uint64_t *h_total_bytes, uint32_t *h_last_assignment);
 
+/* ---- pipelined encoding from host memory, over one or several GPUs ------------------------------
+ * Replaces, for a client whose PCM arrives in host memory, the loop "process_frame_ per block as soon as
+ * blocksize+1 samples are buffered" (stream_encoder.c:1973-2105, :2866-2923) and the hand-over of each frame
+ * (write_bitbuffer_ :2384-2429): batches of `batch_frames` blocks are kept in flight so that the upload of one
+ * batch, the kernels of the one before and the download of the one before that overlap, and successive batches
+ * go to the listed devices in turn (frame ranges sharded over the GPUs of a node; the host puts them back in
+ * order).  For loose mid/side streams batch_frames is rounded up to whole decision periods (:2958-2967) so that
+ * no batch depends on the one before.  `depth` = batches in flight per device (2..8).
+ *
+ * Use: p = fill_buffer() (pinned host memory for one batch, layout pcm_format(): int16 for streams of at most
+ * 16 bits, else int32; NULL while every slot is in flight) -> write up to batch_frames * blocksize wide samples
+ * -> submit(nsamples, final_block, first_frame_number) -> ... -> collect() (waits for the oldest batch; the
+ * pointers stay valid until release()) -> release().  Batches come back in submission order. */
+typedef struct flacamd_pipe flacamd_pipe;
+int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth);
+void flacamd_pipe_destroy(flacamd_pipe *p);
+int flacamd_pipe_pcm_format(const flacamd_pipe *p);
+uint32_t flacamd_pipe_batch_frames(const flacamd_pipe *p);
+uint32_t flacamd_pipe_slots(const flacamd_pipe *p);          /* ndevices * depth */
+uint32_t flacamd_pipe_in_flight(const flacamd_pipe *p);      /* submitted and not yet released */
+size_t flacamd_pipe_max_batch_bytes(const flacamd_pipe *p);  /* size bound of one batch's frames (see flacamd_encoder_max_output_bytes) */
+const flacamd_params *flacamd_pipe_params(const flacamd_pipe *p);
+void *flacamd_pipe_fill_buffer(flacamd_pipe *p);
+void *flacamd_pipe_slot_buffer(flacamd_pipe *p, uint32_t slot); /* batch q (counted from 0) is filled in slot q % slots */
+int flacamd_pipe_submit(flacamd_pipe *p, uint64_t nsamples, int final_block, uint32_t first_frame_number);
+int flacamd_pipe_ready(flacamd_pipe *p);                     /* 1: collect() would not wait, 0: it would */
+int flacamd_pipe_collect(flacamd_pipe *p, const uint8_t **h_frames, const uint32_t **h_frame_bytes, uint32_t *nframes,
+	uint64_t *total_bytes, const void **h_pcm, uint64_t *nsamples, uint32_t *first_frame_number);
+int flacamd_pipe_release(flacamd_pipe *p);
+/* A whole run of blocks from ordinary host memory through the pipe in one call (copies into the pinned buffers,
+ * narrowing int32 to int16 where the stream allows): frames back to back in h_out, one size per frame. */
+int flacamd_pipe_encode_host(flacamd_pipe *p, const void *h_pcm, int pcm_format, uint64_t nsamples, int final_block, uint32_t first_frame_number,
+	uint8_t *h_out, size_t out_cap, uint32_t *h_frame_bytes, size_t frame_cap, uint64_t *h_total_bytes, uint32_t *h_nframes);
+/* int32 samples of a stream of at most 16 bits -> int16 (what format_input does for the CLI, src/flac/encode.c:2338, the other way round) */
+void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues);
+
 /* White-box views of the last batch for parity tests (device -> host copies):
  *   what = 0: float autoc[num_apod][max_lpc_order+1][nsignals]   (lpc.c:63-110 outputs)
  *   what = 1: uint64 fixed_err[5][nsignals]                       (fixed.c:234-243 sums)

@@ -237,6 +237,13 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *encoder);
 /* HIP device to run on (default 0) and frames per engine batch (default 1024). */
 FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *encoder, int device);
 FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *encoder, unsigned frames);
+/* Several GPUs of one node: batches of frames go to the listed devices in turn and their frames are written out
+ * in stream order (frames are independent given their samples and number, stream_encoder.c:2866-2923; batch
+ * borders are kept on loose mid/side decision periods, :2958-2967).  The same id may be listed more than once. */
+FLAC__bool flacamd_stream_encoder_set_devices(FLAC__StreamEncoder *encoder, unsigned num_devices, const int *device_ids);
+/* Batches kept in flight per device (2..8, default 3 on one device, 2 on several): while one is coded, the next
+ * is uploaded and filled and the one before is downloaded. */
+FLAC__bool flacamd_stream_encoder_set_batches_in_flight(FLAC__StreamEncoder *encoder, unsigned per_device);
 
 /* ======================================================================================
  * libFLAC-style stream decoder object over the frame-parallel device decoder.

@@ -181,9 +181,24 @@ def test_write_error_stops_the_encoder(gpu_engine):
     assert e.set_compression_level(3) and e.set_batch_frames(2)
     assert e.init() == stream.INIT_OK
     pcm = synth.music_like(1.0, seed=5)[:4096 * 6]
-    assert not e.process_interleaved(pcm)
+    # batches are in flight while later samples arrive, so the refused write is reported by the call during which
+    # the batch comes back: this process call, a later one, or finish() at the latest - never lost
+    ok = e.process_interleaved(pcm)
+    for _ in range(200):
+        if not ok:
+            break
+        ok = e.process_interleaved(pcm[:4096 * 2])
+    assert not ok
     assert e.get_state() == stream.CLIENT_ERROR        # write_frame_ (:2513-2516)
+    assert [w for w in e.writes if w[1]] == [(w[0], 4096, i) for i, w in enumerate([w for w in e.writes if w[1]])] and len([w for w in e.writes if w[1]]) == 2
     assert not e.process_interleaved(pcm[:10])
+    assert not e.finish() and e.get_state() == stream.CLIENT_ERROR
+    e.close()
+    # and when nothing more is handed over, finish() reports it
+    e = Failing(seekable=False)
+    assert e.set_compression_level(3) and e.set_batch_frames(2)
+    assert e.init() == stream.INIT_OK
+    e.process_interleaved(pcm)
     assert not e.finish() and e.get_state() == stream.CLIENT_ERROR
     e.close()
 
