@@ -88,8 +88,14 @@ def cpu_baseline(base_pcm, budget_s=12.0):
     # all host cores: one process per core of this job's CPU share
     try:
         import multiprocessing as mp
-        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-        cores = max(1, min(cores, 16))
+        # one process per core this job may use: the box sets OMP_NUM_THREADS to its CPU share (16 for one GPU) while
+        # os.cpu_count() reports the whole machine; both are recorded
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            affinity = os.cpu_count() or 1
+        share = int(os.environ.get("OMP_NUM_THREADS", "0")) or affinity
+        cores = max(1, min(share, affinity))
         ctx = mp.get_context("fork")
         reps = 3
         t1 = time.perf_counter()
@@ -99,11 +105,36 @@ def cpu_baseline(base_pcm, budget_s=12.0):
         for p in procs:
             p.join()
         dt = time.perf_counter() - t1
-        out["all_cores"] = {"value": round(cores * reps * n / dt / 1e6, 3), "cores": cores,
+        out["all_cores"] = {"value": round(cores * reps * n / dt / 1e6, 3), "cores": cores, "host_cpu_count": os.cpu_count(), "affinity": affinity,
+                            "cpu_share_env": os.environ.get("OMP_NUM_THREADS"),
                             "sample": "%d processes x %d passes of the same programme, wall clock incl. process start" % (cores, reps)}
     except Exception as ex:  # the single-stream figure stands on its own
         out["all_cores"] = {"error": str(ex)}
     return out
+
+
+def api_rates(base_pcm, minutes):
+    """Rates through the boundary a libFLAC client sees (tools/api_rate.cpp, a compiled C++ client of the
+    C ABI run as a child process): PCM in pageable host memory as int32, frames to a C write callback.
+    PCIe-inclusive, so never `value`."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "bin", "api_rate")
+    if not os.path.exists(exe):
+        return {"error": "tools/bin/api_rate not built"}
+    with tempfile.NamedTemporaryFile(suffix=".raw", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as f:
+        base_pcm.astype(np.int16).tofile(f)
+        f.flush()
+        try:
+            out = subprocess.run([exe, f.name, str(minutes), "8", "2048", "1"], capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            return {"error": "api_rate timed out"}
+    if out.returncode != 0:
+        return {"error": "api_rate rc=%d: %s" % (out.returncode, out.stderr[-300:])}
+    try:
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except ValueError:
+        return {"error": "api_rate output not understood: %s" % out.stdout[-200:]}
 
 
 _WORK = {}
@@ -130,6 +161,7 @@ def main():
     ap.add_argument("--minutes", type=int, default=60, help="audio minutes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-api", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -147,6 +179,11 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu = cpu_baseline(base)
+
+    # API-level rates, in a child process of its own, before this process touches the GPU
+    api = None
+    if not args.no_api and world == 1 and rank == 0:
+        api = api_rates(base, args.minutes)
 
     # rehearsal of the N > 1 path on a box with one GPU: all ranks on device 0, rendezvous and reductions over gloo
     rehearsal = os.environ.get("FLACAMD_BENCH_REHEARSAL") == "1"
@@ -243,7 +280,7 @@ def main():
             "value": round(value, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "flac -8 (LPC order 12, blocksize 4096, mid/side, tukey(0.5)) on %d min of 16/44.1 stereo per GPU, PCM resident in HBM as int16" % args.minutes,
+            "config": {"workload": "flac -8 (LPC order 12, blocksize 4096, mid/side, tukey(0.5)) on %d min of 16/44.1 stereo per GPU (one seeded 60 s synthetic programme tiled %d times), PCM resident in HBM as int16" % (args.minutes, args.minutes),
                        "frames_per_gpu": nframes, "wide_samples_per_gpu": nsamples, "parallelism": "frame ranges x%d" % world,
                        "compressed_bytes_per_gpu": total_bytes, "ratio": round(total_bytes / (nsamples * 4), 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -256,6 +293,8 @@ def main():
             line["decode"] = decode
         if size_delta is not None:
             line["size_delta_vs_ref"] = round(size_delta, 6)
+        if api is not None:
+            line["api"] = api
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

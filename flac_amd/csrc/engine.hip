@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -589,6 +590,44 @@ extern "C" long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h
 
 struct PipeMeta { uint32_t status, last_assignment; uint64_t total; };
 
+// Pinned host buffers are expensive to make and, above all, to touch for the first time (the first pass over fresh
+// pinned pages runs at a few GB/s), which is what a short stream would spend most of its time on.  The buffers of a
+// destroyed pipe therefore go to a small process-wide free list and the next pipe of the same geometry takes them
+// over, warm.  At most PIN_CACHE_ENTRIES buffers / PIN_CACHE_BYTES are kept; flacamd_pipe_trim() releases them.
+#define PIN_CACHE_ENTRIES 32
+#define PIN_CACHE_BYTES ((size_t)1 << 30)
+static std::mutex g_pin_lock;
+static struct { void *p; size_t bytes; } g_pin[PIN_CACHE_ENTRIES];
+static size_t g_pin_total;
+
+static hipError_t pinned_alloc(void **out, size_t bytes)
+{
+	{
+		std::lock_guard<std::mutex> hold(g_pin_lock);
+		for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p && g_pin[i].bytes == bytes) { *out = g_pin[i].p; g_pin[i].p = 0; g_pin_total -= bytes; return hipSuccess; }
+	}
+	return hipHostMalloc(out, bytes, hipHostMallocPortable);
+}
+
+static void pinned_free(void *p, size_t bytes)
+{
+	if(!p) return;
+	{
+		std::lock_guard<std::mutex> hold(g_pin_lock);
+		if(g_pin_total + bytes <= PIN_CACHE_BYTES) for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(!g_pin[i].p) { g_pin[i].p = p; g_pin[i].bytes = bytes; g_pin_total += bytes; return; }
+	}
+	(void)hipHostFree(p);
+}
+
+static void pipe_trim_parked();
+extern "C" void flacamd_pipe_trim(void)
+{
+	pipe_trim_parked();
+	std::lock_guard<std::mutex> hold(g_pin_lock);
+	for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p) { (void)hipHostFree(g_pin[i].p); g_pin[i].p = 0; g_pin[i].bytes = 0; }
+	g_pin_total = 0;
+}
+
 struct PipeSlot {
 	uint32_t lane;
 	void *h_pcm, *d_pcm;
@@ -608,19 +647,37 @@ struct flacamd_pipe {
 	size_t pcm_bytes, out_cap;
 	PipeLane *lanes; PipeSlot *slots;
 	uint64_t head, tail;            // batches submitted / released so far; slot of batch q is q % nslots
+	flacamd_params key_params; int key_devices[64]; uint32_t key_batch, key_depth;   // what it was created with
+	int complete;
 };
 
 extern "C" void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues);
 
+// A pipe that is destroyed while idle is parked instead (PIPE_PARKED at most) and handed to the next
+// flacamd_pipe_create with the same devices, parameters, batch size and depth: a process that codes stream after
+// stream then pays for streams, device memory, pinned memory and the encoder workspaces once.
+#define PIPE_PARKED 2
+static flacamd_pipe *g_parked[PIPE_PARKED];
+static void pipe_free(flacamd_pipe *pp);
+
 extern "C" void flacamd_pipe_destroy(flacamd_pipe *pp)
 {
 	if(!pp) return;
+	if(pp->complete && pp->head == pp->tail) {
+		std::lock_guard<std::mutex> hold(g_pin_lock);
+		for(int i = 0; i < PIPE_PARKED; i++) if(!g_parked[i]) { g_parked[i] = pp; return; }
+	}
+	pipe_free(pp);
+}
+
+static void pipe_free(flacamd_pipe *pp)
+{
 	for(uint32_t i = 0; pp->slots && i < pp->nslots; i++) {
 		PipeSlot &s = pp->slots[i];
 		if(pp->lanes && pp->lanes[s.lane].enc) (void)hipSetDevice(pp->lanes[s.lane].device);
 		if(s.ev_done) { (void)hipEventSynchronize(s.ev_done); }
-		if(s.h_pcm) (void)hipHostFree(s.h_pcm);
-		if(s.h_out) (void)hipHostFree(s.h_out);
+		pinned_free(s.h_pcm, pp->pcm_bytes);
+		pinned_free(s.h_out, pp->out_cap);
 		if(s.h_fb) (void)hipHostFree(s.h_fb);
 		if(s.h_meta) (void)hipHostFree(s.h_meta);
 		if(s.d_pcm) (void)hipFree(s.d_pcm);
@@ -649,8 +706,17 @@ extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint3
 	*out = 0;
 	if(depth < 2) depth = 2;
 	if(depth > 8) depth = 8;
+	{
+		std::lock_guard<std::mutex> hold(g_pin_lock);
+		for(int i = 0; i < PIPE_PARKED; i++) {
+			flacamd_pipe *q = g_parked[i];
+			if(q && q->nlanes == ndevices && q->key_batch == batch_frames && q->key_depth == depth && 0 == memcmp(&q->key_params, params, sizeof *params)
+				&& 0 == memcmp(q->key_devices, devices, sizeof(int) * ndevices)) { g_parked[i] = 0; *out = q; return FLACAMD_OK; }
+		}
+	}
 	flacamd_pipe *pp = (flacamd_pipe*)calloc(1, sizeof *pp);
 	if(!pp) return FLACAMD_E_OUT_OF_MEMORY;
+	pp->key_params = *params; memcpy(pp->key_devices, devices, sizeof(int) * ndevices); pp->key_batch = batch_frames; pp->key_depth = depth;
 	pp->p = *params;
 	int rc = flacamd_params_resolve(&pp->p);
 	if(rc != FLACAMD_OK) { free(pp); return rc; }
@@ -680,8 +746,8 @@ extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint3
 		PipeSlot &s = pp->slots[i];
 		s.lane = i % pp->nlanes;
 		hipError_t he = hipSetDevice(pp->lanes[s.lane].device);
-		if(he == hipSuccess) he = hipHostMalloc(&s.h_pcm, pp->pcm_bytes, hipHostMallocPortable);
-		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_out, pp->out_cap, hipHostMallocPortable);
+		if(he == hipSuccess) he = pinned_alloc(&s.h_pcm, pp->pcm_bytes);
+		if(he == hipSuccess) he = pinned_alloc((void**)&s.h_out, pp->out_cap);
 		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_fb, (size_t)batch_frames * 4u, hipHostMallocPortable);
 		if(he == hipSuccess) he = hipHostMalloc((void**)&s.h_meta, sizeof(PipeMeta), hipHostMallocPortable);
 		if(he == hipSuccess) he = hipMalloc(&s.d_pcm, pp->pcm_bytes);
@@ -692,8 +758,19 @@ extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint3
 		if(he == hipSuccess) he = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
 		if(he != hipSuccess) { rc = hip_fail(he, "pipe slot allocation"); flacamd_pipe_destroy(pp); return rc; }
 	}
+	pp->complete = 1;
 	*out = pp;
 	return FLACAMD_OK;
+}
+
+static void pipe_trim_parked()
+{
+	flacamd_pipe *take[PIPE_PARKED];
+	{
+		std::lock_guard<std::mutex> hold(g_pin_lock);
+		for(int i = 0; i < PIPE_PARKED; i++) { take[i] = g_parked[i]; g_parked[i] = 0; }
+	}
+	for(int i = 0; i < PIPE_PARKED; i++) if(take[i]) pipe_free(take[i]);
 }
 
 extern "C" int flacamd_pipe_pcm_format(const flacamd_pipe *pp) { return pp ? pp->pcm_format : FLACAMD_E_INVALID_ARGUMENT; }

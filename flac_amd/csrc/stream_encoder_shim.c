@@ -67,6 +67,10 @@ struct FLAC__StreamEncoder {
 	pthread_mutex_t md5_lock; pthread_cond_t md5_data, md5_space;
 	uint64_t md5_produced, md5_hashed; /* wide samples written into upload buffers / hashed so far */
 	uint8_t *md5_scratch;
+	/* helpers for large process_interleaved calls: the copy out of the client's buffer (narrowing to int16) is what
+	 * bounds a host-fed stream once everything else overlaps; one thread moves about 4 G samples/s, the upload 14 */
+	unsigned fill_threads;            /* threads a large call is spread over, the caller included (default 4) */
+	struct fill_pool *pool;
 	/* client metadata blocks (:1711-1741: the array is ours, the blocks are the client's) and seek table tracking (:2458-2485) */
 	FLAC__StreamMetadata **metadata; unsigned num_metadata;
 	FLAC__StreamMetadata_SeekTable *seek_table; unsigned first_seekpoint_to_check;
@@ -81,13 +85,13 @@ struct FLAC__StreamEncoder {
 
 static void set_defaults(FLAC__StreamEncoder *e) /* set_defaults_, :2107-2160 */
 {
-	int devices[64]; const unsigned ndev = e->ndevices, batch = e->batch_frames, depth = e->depth;
+	int devices[64]; const unsigned ndev = e->ndevices, batch = e->batch_frames, depth = e->depth, fillt = e->fill_threads;
 	const struct verify_stats keep = e->vstats; /* the reference only clears these at init (:1012-1017) */
 	memcpy(devices, e->devices, sizeof devices);
 	free(e->metadata);
 	memset(e, 0, sizeof *e);
 	e->vstats = keep; e->vstate = FLAC__STREAM_DECODER_UNINITIALIZED; /* what the finished verify decoder reports (:1351) */
-	memcpy(e->devices, devices, sizeof devices); e->ndevices = ndev ? ndev : 1u; e->batch_frames = batch ? batch : 1024u; e->depth = depth;
+	memcpy(e->devices, devices, sizeof devices); e->ndevices = ndev ? ndev : 1u; e->batch_frames = batch ? batch : 2048u; e->depth = depth; e->fill_threads = fillt ? fillt : 4u;
 	e->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
 	e->verify = 0; e->streamable_subset = 1; e->do_md5 = 1;
 	e->p.channels = 2; e->p.bits_per_sample = 16; e->p.sample_rate = 44100; e->p.blocksize = 0;
@@ -102,11 +106,13 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 }
 
 static void md5_stop(FLAC__StreamEncoder *e);
+static void pool_stop(FLAC__StreamEncoder *e);
 static void *md5_worker(void *arg);
 
 static void free_buffers(FLAC__StreamEncoder *e)
 {
 	md5_stop(e);
+	pool_stop(e);
 	if(e->pipe) { flacamd_pipe_destroy(e->pipe); e->pipe = 0; }
 	if(e->vdec) { flacamd_decoder_destroy(e->vdec); e->vdec = 0; }
 	free(e->vpcm); e->vpcm = 0;
@@ -200,6 +206,11 @@ FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *e, unsig
 {
 	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || frames == 0) return 0;
 	e->batch_frames = frames; return 1;
+}
+FLAC__bool flacamd_stream_encoder_set_fill_threads(FLAC__StreamEncoder *e, unsigned threads)
+{
+	if(!e || e->state != FLAC__STREAM_ENCODER_UNINITIALIZED || threads == 0 || threads > 8) return 0;
+	e->fill_threads = threads; return 1;
 }
 FLAC__bool flacamd_stream_encoder_set_batches_in_flight(FLAC__StreamEncoder *e, unsigned per_device)
 {
@@ -697,6 +708,100 @@ static FLAC__bool submit_batch(FLAC__StreamEncoder *e, int final_block)
 	return 1;
 }
 
+/* ---- helper threads for the copy of a large call */
+#define FILL_MAX_THREADS 8
+#define FILL_MIN_VALUES ((size_t)1 << 19)   /* below this a call is copied by the caller alone */
+struct fill_part { const int32_t *src; void *dst; size_t nvalues; };
+struct fill_pool {
+	pthread_t th[FILL_MAX_THREADS]; unsigned nth; int narrow;
+	pthread_mutex_t lock; pthread_cond_t go, done;
+	unsigned generation, pending; int quit;
+	struct fill_part part[FILL_MAX_THREADS];
+	struct fill_arg { struct fill_pool *pool; unsigned index; } arg[FILL_MAX_THREADS];
+};
+
+static void fill_copy(int narrow, const struct fill_part *p)
+{
+	if(narrow) flacamd_pcm_narrow((int16_t*)p->dst, p->src, p->nvalues);
+	else memcpy(p->dst, p->src, sizeof(int32_t) * p->nvalues);
+}
+
+static void *fill_worker(void *argp)
+{
+	struct fill_arg *a = (struct fill_arg*)argp; struct fill_pool *pl = a->pool;
+	unsigned seen = 0;
+	pthread_mutex_lock(&pl->lock);
+	for(;;) {
+		while(pl->generation == seen && !pl->quit) pthread_cond_wait(&pl->go, &pl->lock);
+		if(pl->quit) break;
+		seen = pl->generation;
+		pthread_mutex_unlock(&pl->lock);
+		fill_copy(pl->narrow, &pl->part[a->index]);
+		pthread_mutex_lock(&pl->lock);
+		if(--pl->pending == 0) pthread_cond_signal(&pl->done);
+		/* a client streaming large buffers calls again within microseconds: look out for the next job for a short
+		 * while before going to sleep (a sleeping thread takes tens of microseconds to wake, as long as its share of a call) */
+		{
+			int spin;
+			pthread_mutex_unlock(&pl->lock);
+			for(spin = 0; spin < 4000 && __atomic_load_n(&pl->generation, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&pl->quit, __ATOMIC_ACQUIRE); spin++) __builtin_ia32_pause();
+			pthread_mutex_lock(&pl->lock);
+		}
+	}
+	pthread_mutex_unlock(&pl->lock);
+	return 0;
+}
+
+static void pool_stop(FLAC__StreamEncoder *e)
+{
+	struct fill_pool *pl = e->pool; unsigned i;
+	if(!pl) return;
+	pthread_mutex_lock(&pl->lock); pl->quit = 1; pthread_cond_broadcast(&pl->go); pthread_mutex_unlock(&pl->lock);
+	for(i = 0; i < pl->nth; i++) pthread_join(pl->th[i], 0);
+	pthread_mutex_destroy(&pl->lock); pthread_cond_destroy(&pl->go); pthread_cond_destroy(&pl->done);
+	free(pl); e->pool = 0;
+}
+
+/* copy nvalues interleaved samples into the batch being filled, spread over the helper threads when the call is large */
+static void fill_values(FLAC__StreamEncoder *e, void *dst, const int32_t *src, size_t nvalues)
+{
+	struct fill_part whole; unsigned i, helpers;
+	whole.src = src; whole.dst = dst; whole.nvalues = nvalues;
+	if(nvalues < FILL_MIN_VALUES || e->fill_threads < 2) { fill_copy(e->fmt16, &whole); return; }
+	if(!e->pool) { /* started by the first large call */
+		struct fill_pool *pl = (struct fill_pool*)calloc(1, sizeof *pl);
+		if(!pl || pthread_mutex_init(&pl->lock, 0) || pthread_cond_init(&pl->go, 0) || pthread_cond_init(&pl->done, 0)) { free(pl); e->fill_threads = 1; fill_copy(e->fmt16, &whole); return; }
+		pl->narrow = e->fmt16;
+		for(i = 0; i + 1 < e->fill_threads && i < FILL_MAX_THREADS; i++) {
+			pl->arg[i].pool = pl; pl->arg[i].index = i;
+			if(pthread_create(&pl->th[i], 0, fill_worker, &pl->arg[i])) break;
+			pl->nth++;
+		}
+		e->pool = pl;
+	}
+	helpers = e->pool->nth;
+	if(helpers == 0) { fill_copy(e->fmt16, &whole); return; }
+	{
+		struct fill_pool *pl = e->pool;
+		const size_t per = (nvalues / (helpers + 1) + 63) & ~(size_t)63;
+		const size_t w = e->fmt16 ? 2u : 4u;
+		size_t at = 0;
+		pthread_mutex_lock(&pl->lock);
+		for(i = 0; i < helpers; i++) {
+			size_t n = per; if(at + n > nvalues) n = nvalues - at;
+			pl->part[i].src = src + at; pl->part[i].dst = (uint8_t*)dst + at * w; pl->part[i].nvalues = n; at += n;
+		}
+		pl->pending = helpers; pl->generation++;
+		pthread_cond_broadcast(&pl->go);
+		pthread_mutex_unlock(&pl->lock);
+		whole.src = src + at; whole.dst = (uint8_t*)dst + at * w; whole.nvalues = nvalues - at;
+		fill_copy(e->fmt16, &whole);
+		pthread_mutex_lock(&pl->lock);
+		while(pl->pending) pthread_cond_wait(&pl->done, &pl->lock);
+		pthread_mutex_unlock(&pl->lock);
+	}
+}
+
 /* Room for samples in the batch being filled.  The reference codes a block once blocksize+1 samples are known
  * (:2006, :2062): a full batch is only submitted when a later sample has arrived, so that finish() can still
  * code its last block as the final one.  Returns the number of wide samples that fit (at least 1), 0 on error. */
@@ -715,8 +820,7 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 		size_t n = room(e);
 		if(n == 0) return 0;
 		if(n > samples - done) n = samples - done;
-		if(e->fmt16) flacamd_pcm_narrow((int16_t*)e->fill + e->filled * ch, buffer + done * ch, n * ch);
-		else memcpy((int32_t*)e->fill + e->filled * ch, buffer + done * ch, sizeof(int32_t) * n * ch);
+		fill_values(e, e->fill + e->filled * ch * (e->fmt16 ? 2u : 4u), buffer + done * ch, n * ch);
 		e->filled += n; done += n;
 		md5_publish(e, n);
 	}

@@ -153,6 +153,9 @@ int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, u
 typedef struct flacamd_pipe flacamd_pipe;
 int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth);
 void flacamd_pipe_destroy(flacamd_pipe *p);
+/* The pinned buffers of destroyed pipes are kept (at most 1 GiB) for the next pipe of the same geometry, because
+ * fresh pinned memory is slow to touch for the first time; this releases them. */
+void flacamd_pipe_trim(void);
 int flacamd_pipe_pcm_format(const flacamd_pipe *p);
 uint32_t flacamd_pipe_batch_frames(const flacamd_pipe *p);
 uint32_t flacamd_pipe_slots(const flacamd_pipe *p);          /* ndevices * depth */

@@ -234,7 +234,7 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *encoder
 FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *encoder);
 
 /* ---- additions of this implementation (no counterpart in the reference) ---- */
-/* HIP device to run on (default 0) and frames per engine batch (default 1024). */
+/* HIP device to run on (default 0) and frames per engine batch (default 2048). */
 FLAC__bool flacamd_stream_encoder_set_device(FLAC__StreamEncoder *encoder, int device);
 FLAC__bool flacamd_stream_encoder_set_batch_frames(FLAC__StreamEncoder *encoder, unsigned frames);
 /* Several GPUs of one node: batches of frames go to the listed devices in turn and their frames are written out
@@ -244,6 +244,9 @@ FLAC__bool flacamd_stream_encoder_set_devices(FLAC__StreamEncoder *encoder, unsi
 /* Batches kept in flight per device (2..8, default 3 on one device, 2 on several): while one is coded, the next
  * is uploaded and filled and the one before is downloaded. */
 FLAC__bool flacamd_stream_encoder_set_batches_in_flight(FLAC__StreamEncoder *encoder, unsigned per_device);
+/* Threads (1..8, default 4, the calling one included) over which the copy of a large process_interleaved call
+ * out of the client's buffer is spread; calls below half a million values are copied by the caller alone. */
+FLAC__bool flacamd_stream_encoder_set_fill_threads(FLAC__StreamEncoder *encoder, unsigned threads);
 
 /* ======================================================================================
  * libFLAC-style stream decoder object over the frame-parallel device decoder.
