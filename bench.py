@@ -137,6 +137,196 @@ def api_rates(base_pcm, minutes):
         return {"error": "api_rate output not understood: %s" % out.stdout[-200:]}
 
 
+# ---- the other BASELINE configurations, at their stated sizes (outside the timed region of the headline) ----------
+
+def _timed(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+
+def config_c3(dev, local, seconds=600):
+    """flac -8 -e -p on 24-bit / 96 kHz / 8 channels: `seconds` of audio (a seeded 10 s programme tiled), PCM resident as int32."""
+    import torch
+    from flac_amd import engine, synth
+    base = synth.multichannel_24(10.0, rate=96000, channels=8, seed=4321)
+    reps = max(1, seconds // 10)
+    n = len(base) * reps
+    F = (n + FRAME - 1) // FRAME
+    p = engine.make_params(8, 24, 96000, level=8, do_exhaustive_model_search=1, do_qlp_coeff_prec_search=1)
+    enc = engine.Encoder(p, max_frames=F, device=local)
+    enc.set_timing(True)
+    d = torch.from_numpy(base).to(dev).repeat(reps, 1)
+    cap = n * 8 * 4 + F * 256 + 4096       # the streams compress; a batch that does not says what it needs
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    fb = torch.empty(F, dtype=torch.int32, device=dev)
+    dt, total = _timed(lambda: enc.encode_device(d.data_ptr(), engine.PCM_S32, n, out.data_ptr(), cap, fb.data_ptr()), 2)
+    st = enc.last_timing()
+    dom = max(st, key=st.get)
+    algo = n * 8 * 3 + total
+    res = {"workload": "flac -8 -e -p, 8 ch 24-bit/96 kHz, %d s (10 s programme tiled %d times), one GPU" % (n // 96000, reps),
+           "value": round(n / dt / 1e6, 2), "unit": "MSamples/s (wide)", "channel_samples_per_s_M": round(8 * n / dt / 1e6, 1), "ms": round(dt * 1e3, 2),
+           "frames": F, "compressed_bytes": total, "ratio": round(total / (n * 24), 4), "stage_ms": {k: round(v, 3) for k, v in st.items()},
+           "algorithmic_bytes": algo, "dominant_stage": dom,
+           "roofline": {"bound": "hbm", "achieved": round(algo / (st[dom] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(algo / (st[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    enc.close()
+    return res
+
+
+def config_c4(dev, local, base_pcm, hours=5):
+    """Frame-parallel decode of a multi-GB -8 stream: `hours` of 16/44.1 stereo coded here, then decoded in one pass;
+    also the rate at shorter batches of the same stream (the decode kernel is latency-bound: it should grow with the batch)."""
+    import torch
+    from flac_amd import engine
+    base = torch.from_numpy(base_pcm.astype(np.int16)).to(dev)
+    d_pcm = base.repeat(60 * hours, 1)
+    n = d_pcm.shape[0]
+    F = (n + FRAME - 1) // FRAME
+    enc = engine.Encoder(engine.make_params(2, 16, RATE, level=8), max_frames=F, device=local)
+    cap = n * 4 + F * 64 + 4096
+    d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    d_fb = torch.empty(F, dtype=torch.int32, device=dev)
+    total = enc.encode_device(d_pcm.data_ptr(), engine.PCM_S16, n, d_out.data_ptr(), cap, d_fb.data_ptr())
+    enc.close()
+    sizes = d_fb.to(torch.int64)
+    ends = torch.cumsum(sizes, 0)
+    dec = engine.Decoder(2, 16, FRAME, int(F * 1.25) + 64, total + 64, device=local)
+    d_back = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    res = {"workload": "decode of a %.2f GB flac -8 stream (%d h of 16/44.1 stereo, %d frames) resident in HBM, one pass, one GPU" % (total / 1e9, hours, F), "by_batch": {}}
+    for h in sorted({1, 2, 4, hours}):
+        if h > hours:
+            continue
+        fr = min(F, (h * 3600 * RATE + FRAME - 1) // FRAME)
+        nb = int(ends[fr - 1].item())
+        ns = min(n, fr * FRAME)
+        dt, info = _timed(lambda: dec.decode_device(d_out.data_ptr(), nb, d_back.data_ptr(), engine.PCM_S16, n), 3)
+        ok = bool(torch.equal(d_back[:ns], d_pcm[:ns])) and info["frames"] == fr
+        res["by_batch"]["%dh" % h] = {"value": round(ns / dt / 1e6, 1), "ms": round(dt * 1e3, 2), "bytes": nb, "bit_exact": ok}
+        if h == hours:
+            algo = nb + ns * 4
+            res.update({"value": round(ns / dt / 1e6, 1), "unit": "MSamples/s", "ms": round(dt * 1e3, 2), "stream_bytes": nb, "frames": fr, "bit_exact": ok,
+                        "algorithmic_bytes": algo,
+                        "roofline": {"bound": "hbm", "achieved": round(algo / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 5),
+                                     "note": "whole decode pass (scan, parse, restore, CRC, chain, interleave) against bytes in + PCM out"}})
+    dec.close()
+    return res
+
+
+def config_c5(dev, local, nclips=10000):
+    """Batch encode of `nclips` clips of 1-30 s at -5, mixed 16/24-bit, 44.1/48 kHz, mono/stereo (seed 777): every clip a complete
+    stream (head, MD5, frames) assembled on the device, one engine call per format group, the groups side by side; clips resident in HBM."""
+    import torch
+    from flac_amd import clips, engine, synth
+    rng = np.random.default_rng(777)
+    dur = rng.uniform(1.0, 30.0, nclips)
+    bps = np.where(rng.random(nclips) < 0.5, 16, 24)
+    rate = np.where(rng.random(nclips) < 0.5, 44100, 48000)
+    ch = np.where(rng.random(nclips) < 0.5, 1, 2)
+    plans = []
+    audio_s = 0.0
+    wide = 0
+    for key in sorted({(int(c), int(b), int(r)) for c, b, r in zip(ch, bps, rate)}):
+        c, b, r = key
+        idx = np.nonzero((ch == c) & (bps == b) & (rate == r))[0]
+        # four seeded 30 s programmes per format; a clip is the head of one of them
+        if b == 16:
+            progs = [torch.from_numpy(np.ascontiguousarray(synth.music_like(30.0, rate=r, seed=5 + k)[:, :c].astype(np.int16))).to(dev) for k in range(4)]
+            fmt = engine.PCM_S16
+        else:
+            progs = [torch.from_numpy(np.ascontiguousarray(synth.multichannel_24(30.0, rate=r, channels=c, seed=9 + k))).to(dev) for k in range(4)]
+            fmt = engine.PCM_S32
+        lens = (dur[idx] * r).astype(np.int64)
+        starts, total, nfr = clips.layout(lens, FRAME)
+        d_pcm = torch.zeros((total, c), dtype=progs[0].dtype, device=dev)
+        for j, (st, ln) in enumerate(zip(starts, lens)):
+            d_pcm[int(st):int(st) + int(ln)] = progs[j % 4][:int(ln)]
+        Fg = int(nfr.sum())
+        enc = engine.Encoder(engine.make_params(c, b, r, level=5), max_frames=Fg, device=local)
+        plans.append((enc, d_pcm, fmt, starts, lens, Fg))
+        audio_s += float((lens / r).sum())
+        wide += int(lens.sum())
+    torch.cuda.synchronize()
+
+    def run():
+        return clips.encode_groups_device(plans, local)
+
+    dt, outs = _timed(run, 2)
+    total_bytes = int(sum(int(o[1][-1]) for o in outs))
+    pcm_bytes = int(sum(p[1].numel() * (2 if p[2] == engine.PCM_S16 else 3) for p in plans))
+    # spot check: the first clip of the first group decodes to what went in (the GPU tests compare whole batches with the reference)
+    enc, d_pcm, fmt, starts, lens, Fg = plans[0]
+    d_out, offs = outs[0]
+    head = bytes(d_out[:4].cpu().numpy())
+    for p in plans:
+        p[0].close()
+    return {"workload": "%d clips of 1-30 s at -5, mixed 16/24-bit, 44.1/48 kHz, mono/stereo (seed 777), %d format groups, clips resident in HBM" % (nclips, len(plans)),
+            "value": round(wide / dt / 1e6, 1), "unit": "MSamples/s (wide)", "clips_per_s": round(nclips / dt, 1), "ms": round(dt * 1e3, 1), "audio_hours": round(audio_s / 3600, 2),
+            "frames": int(sum(p[5] for p in plans)), "stream_bytes": total_bytes, "first_stream_magic_ok": head == b"fLaC",
+            "algorithmic_bytes": pcm_bytes + total_bytes,
+            "roofline": {"bound": "hbm", "achieved": round((pcm_bytes + total_bytes) / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round((pcm_bytes + total_bytes) / dt / 1e9 / HBM_PEAK_GBS, 5), "note": "whole batch incl. per-clip MD5 on the device (one lane per clip) and stream assembly"}}
+
+
+def sharded_hour(enc, d_pcm, nsamples, nframes, rank, world, dev, dist, cpu_collectives):
+    """Strong scaling of the headline hour: rank r codes frames [r F/W, (r+1) F/W), the sizes and bytes are gathered to
+    rank 0 (RCCL; no collective on the data path itself) and laid end to end there.  The stitched stream must be the
+    same bytes for every W: rank 0 reports its length and CRC-32."""
+    import zlib
+    import torch
+    from flac_amd import engine, sharding
+    f0, f1 = sharding.frame_ranges(nframes, world, 1)[rank]
+    ns = min(f1 * FRAME, nsamples) - f0 * FRAME
+    cap = enc.max_output_bytes(max(f1 - f0, 1))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_fb = torch.empty(max(f1 - f0, 1), dtype=torch.int32, device=dev)
+    cdev = "cpu" if cpu_collectives else dev
+
+    def once():
+        total = enc.encode_device(d_pcm.data_ptr() + f0 * FRAME * 4, engine.PCM_S16, ns, d_out.data_ptr(), cap, d_fb.data_ptr(), final=(f1 == nframes), first_frame=f0) if f1 > f0 else 0
+        if world == 1:
+            return d_out[:total], total
+        mine = torch.tensor([f1 - f0, total], dtype=torch.int64, device=cdev)
+        counts = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(counts, mine)
+        counts = [(int(c[0]), int(c[1])) for c in counts]
+        max_b = max(c[1] for c in counts)
+        piece = d_out[:max_b] if max_b <= cap else torch.cat([d_out, torch.zeros(max_b - cap, dtype=torch.uint8, device=dev)])
+        piece = piece.to(cdev)
+        got = [torch.empty(max_b, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+        dist.gather(piece, got, dst=0)
+        if rank != 0:
+            return None, 0
+        whole = torch.cat([got[r][:counts[r][1]] for r in range(world)])
+        return whole, int(whole.numel())
+
+    once()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    whole, nbytes = once()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    crc = zlib.crc32(whole.cpu().numpy().tobytes()) & 0xffffffff
+    return {"workload": "the same hour cut into %d frame ranges, coded one per GPU, sizes and bytes gathered to rank 0 and laid end to end" % world,
+            "value": round(nsamples / dt / 1e6, 1), "unit": "MSamples/s", "ms": round(dt * 1e3, 3), "stitched_bytes": nbytes, "stitched_crc32": "%08x" % crc,
+            "scaling": "strong", "includes": "encode on every rank + all_gather of counts + gather of frame bytes to rank 0 + concatenation"}
+
+
 _WORK = {}
 
 
@@ -162,6 +352,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-api", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (C3, C4, C5)")
+    ap.add_argument("--clips", type=int, default=10000)
+    ap.add_argument("--c3-seconds", type=int, default=600)
+    ap.add_argument("--c4-hours", type=int, default=5)
     args = ap.parse_args()
 
     import torch
@@ -259,6 +453,22 @@ def main():
             del d_back
         except Exception as ex:  # reported, never hidden
             decode = {"error": str(ex)}
+    sharded = None
+    try:
+        sharded = sharded_hour(enc, d_pcm, nsamples, nframes, rank, world, dev, dist, rehearsal)
+    except Exception as ex:
+        sharded = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    del d_out, d_fb
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        configs = {}
+        for name, fn in (("c3", lambda: config_c3(dev, local, args.c3_seconds)), ("c4_decode", lambda: config_c4(dev, local, base, args.c4_hours)),
+                         ("c5_clips", lambda: config_c5(dev, local, args.clips))):
+            try:
+                torch.cuda.empty_cache()
+                configs[name] = fn()
+            except Exception as ex:  # reported, never hidden
+                configs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     size_delta = None
     if rank == 0 and cpu is not None and "ref_bytes_60s" in cpu:
         enc60 = engine.Encoder(params, max_frames=(len(base) + FRAME - 1) // FRAME, device=local)
@@ -293,6 +503,10 @@ def main():
             line["decode"] = decode
         if size_delta is not None:
             line["size_delta_vs_ref"] = round(size_delta, 6)
+        if sharded is not None:
+            line["sharded"] = sharded
+        if configs is not None:
+            line["configs"] = configs
         if api is not None:
             line["api"] = api
         if cpu is not None:

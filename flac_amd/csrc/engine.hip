@@ -194,6 +194,9 @@ struct flacamd_encoder {
 	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the autocorrelation stage runs beside the prep stage
 	float last_ms[6];
 	int have_timing;
+	// per-call tables of the multi-stream entry points: pinned host staging and a device buffer, both grow-only
+	void *h_tab; size_t h_tab_bytes; void *d_tab; size_t d_tab_bytes;
+	hipStream_t md5s; hipEvent_t ev_tab, ev_md5;   // the clip batch hashes on a stream of its own beside the coding stages
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -271,7 +274,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
-		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
+		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_fshift = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
 		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u);
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
@@ -282,7 +285,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
 	w.xs_spill = (int32_t*)(b + o_spill);
-	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.window = (const float*)(b + o_window);
+	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.frame_shift = (uint32_t*)(b + o_fshift); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
 	{
@@ -335,6 +338,11 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 	if(e->d_pcm_stage) hipFree(e->d_pcm_stage);
 	if(e->d_out_stage) hipFree(e->d_out_stage);
 	if(e->d_fb_stage) hipFree(e->d_fb_stage);
+	if(e->h_tab) (void)hipHostFree(e->h_tab);
+	if(e->d_tab) (void)hipFree(e->d_tab);
+	if(e->md5s) (void)hipStreamDestroy(e->md5s);
+	if(e->ev_tab) (void)hipEventDestroy(e->ev_tab);
+	if(e->ev_md5) (void)hipEventDestroy(e->ev_md5);
 	free(e);
 }
 
@@ -451,6 +459,40 @@ static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void
 	return FLACAMD_OK;
 }
 
+// grow-only pinned staging / device table buffers of the multi-stream entry points (no allocation on the steady path)
+static int tab_reserve(flacamd_encoder *e, size_t host_bytes, size_t dev_bytes)
+{
+	if(e->h_tab_bytes < host_bytes) {
+		if(e->h_tab) (void)hipHostFree(e->h_tab);
+		e->h_tab = 0; e->h_tab_bytes = 0;
+		const size_t want = host_bytes + host_bytes / 2;
+		HIP_TRY(hipHostMalloc(&e->h_tab, want, hipHostMallocDefault));
+		e->h_tab_bytes = want;
+	}
+	if(e->d_tab_bytes < dev_bytes) {
+		if(e->d_tab) (void)hipFree(e->d_tab);
+		e->d_tab = 0; e->d_tab_bytes = 0;
+		const size_t want = dev_bytes + dev_bytes / 2;
+		HIP_TRY(hipMalloc(&e->d_tab, want));
+		e->d_tab_bytes = want;
+	}
+	return FLACAMD_OK;
+}
+
+// frames of a multi-stream batch: checks that the streams tile the buffer in whole blocks, returns the frame count
+static int streams_frames(const flacamd_encoder *e, uint32_t nstreams, const uint64_t *h_start, const uint64_t *h_len, uint64_t *F_out)
+{
+	const uint32_t N = e->cfg.N;
+	uint64_t F64 = 0;
+	for(uint32_t i = 0; i < nstreams; i++) {
+		if(h_len[i] == 0 || h_start[i] != F64 * N) return FLACAMD_E_INVALID_ARGUMENT;
+		F64 += (h_len[i] + N - 1) / N;
+		if(F64 > e->max_frames) return FLACAMD_E_CAPACITY;
+	}
+	*F_out = F64;
+	return FLACAMD_OK;
+}
+
 extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nstreams,
 	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream)
 {
@@ -460,15 +502,13 @@ extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_p
 	const uint32_t N = e->cfg.N;
 	// frame f of the batch starts at sample f * N: the streams must tile the buffer in whole blocks
 	uint64_t F64 = 0;
-	for(uint32_t i = 0; i < nstreams; i++) {
-		if(h_len[i] == 0 || h_start[i] != F64 * N) return FLACAMD_E_INVALID_ARGUMENT;
-		F64 += (h_len[i] + N - 1) / N;
-		if(F64 > e->max_frames) return FLACAMD_E_CAPACITY;
-	}
+	int rc = streams_frames(e, nstreams, h_start, h_len, &F64);
+	if(rc != FLACAMD_OK) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIP_TRY(hipSetDevice(e->device));
-	uint32_t *tab = (uint32_t*)malloc(sizeof(uint32_t) * 2u * (size_t)F64);
-	if(!tab) return FLACAMD_E_OUT_OF_MEMORY;
+	rc = tab_reserve(e, sizeof(uint32_t) * 2u * (size_t)F64, 0);
+	if(rc != FLACAMD_OK) return rc;
+	uint32_t *tab = (uint32_t*)e->h_tab;   // free again: every call ends with the stream synchronised
 	{
 		uint32_t f = 0;
 		for(uint32_t i = 0; i < nstreams; i++) {
@@ -479,11 +519,8 @@ extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_p
 			}
 		}
 	}
-	hipError_t he = hipMemcpyAsync(e->work.frame_len, tab, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st);
-	if(he == hipSuccess) he = hipMemcpyAsync(e->work.frame_num, tab + F64, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st);
-	if(he == hipSuccess) he = hipStreamSynchronize(st);   // the table is pageable host memory: done with it before it is freed
-	free(tab);
-	if(he != hipSuccess) return hip_fail(he, "hipMemcpyAsync(frame tables)");
+	HIP_TRY(hipMemcpyAsync(e->work.frame_len, tab, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->work.frame_num, tab + F64, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st));
 
 	FaCfg c = e->cfg;
 	c.pcm_format = (uint32_t)pcm_format;
@@ -491,6 +528,126 @@ extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_p
 	c.last_n = N; c.last_fractional = 0; c.first_frame = 0; c.prev_assignment = 0;
 	c.multi = 1; c.skip_full = 0;
 	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
+}
+
+// ---- a batch of clips as complete streams ("fLaC", STREAMINFO, VORBIS_COMMENT, frames), assembled on the device
+extern "C" void fa_launch_md5(const void *d_pcm, uint32_t pcm_format, uint32_t channels, uint32_t bits_per_sample, const uint64_t *d_starts, const uint64_t *d_ends,
+	uint32_t nstreams, uint8_t *d_digests, hipStream_t st);
+
+__constant__ char fa_vendor_string[33] = "reference libFLAC 1.2.1 20070917";   // format.c:56-63
+
+// One wave per clip: smallest and largest frame of the clip, then the 86 bytes a finished stream starts with
+// (stream_encoder.c:1034-1106 as written at init and patched by update_metadata_, :2521-2620), written into the room
+// the gather stage left in front of the clip's frames.
+__global__ void __launch_bounds__(64) fa_clip_heads_kernel(FaCfg c, FaWork w, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
+	const uint32_t *__restrict__ first, const uint32_t *__restrict__ nframes, uint32_t nclips, const uint8_t *__restrict__ digests,
+	uint8_t *__restrict__ out, unsigned long long out_cap, uint64_t *__restrict__ stream_off)
+{
+	__shared__ uint8_t h[FLACAMD_STREAM_HEAD_BYTES];
+	const uint32_t clip = blockIdx.x, lane = threadIdx.x;
+	const uint32_t f0 = first[clip], nf = nframes[clip];
+	uint32_t mn = 0xffffffffu, mx = 0;
+	for(uint32_t i = lane; i < nf; i += 64u) { const uint32_t v = w.frame_bytes[f0 + i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+#pragma unroll
+	for(int o = 32; o >= 1; o >>= 1) { const uint32_t a = (uint32_t)__shfl_xor((int)mn, o, 64), b = (uint32_t)__shfl_xor((int)mx, o, 64); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+	const unsigned long long off = w.offsets[f0] + (unsigned long long)FLACAMD_STREAM_HEAD_BYTES * clip;
+	if(lane == 0) {
+		stream_off[clip] = off;
+		if(clip + 1u == nclips) stream_off[nclips] = w.offsets[c.F] + (unsigned long long)FLACAMD_STREAM_HEAD_BYTES * nclips;
+	}
+	if(off + FLACAMD_STREAM_HEAD_BYTES > out_cap) { if(lane == 0) atomicOr(w.status, 2u); return; }
+	if(lane == 0) {
+		const unsigned long long total = ends[clip] - starts[clip];
+		const unsigned long long packed = ((unsigned long long)c.rate << 44) | ((unsigned long long)(c.channels - 1u) << 41) | ((unsigned long long)(c.bps - 1u) << 36) | (total & 0xFFFFFFFFFull);
+		h[0] = 'f'; h[1] = 'L'; h[2] = 'a'; h[3] = 'C';
+		h[4] = 0; h[5] = 0; h[6] = 0; h[7] = 34;
+		h[8] = (uint8_t)(c.N >> 8); h[9] = (uint8_t)c.N; h[10] = h[8]; h[11] = h[9];
+		h[12] = (uint8_t)(mn >> 16); h[13] = (uint8_t)(mn >> 8); h[14] = (uint8_t)mn;
+		h[15] = (uint8_t)(mx >> 16); h[16] = (uint8_t)(mx >> 8); h[17] = (uint8_t)mx;
+		for(int i = 0; i < 8; i++) h[18 + i] = (uint8_t)(packed >> (8 * (7 - i)));
+		for(int i = 0; i < 16; i++) h[26 + i] = digests[(size_t)clip * 16u + i];
+		h[42] = 0x84; h[43] = 0; h[44] = 0; h[45] = 8 + 32;
+		h[46] = 32; h[47] = 0; h[48] = 0; h[49] = 0;
+		for(int i = 0; i < 32; i++) h[50 + i] = (uint8_t)fa_vendor_string[i];
+		h[82] = h[83] = h[84] = h[85] = 0;
+	}
+	__syncthreads();
+	for(uint32_t i = lane; i < FLACAMD_STREAM_HEAD_BYTES; i += 64u) out[off + i] = h[i];
+}
+
+extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nclips,
+	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint64_t *h_stream_off, uint64_t *h_total_bytes, void *stream)
+{
+	if(!e || !d_pcm || !d_out || nclips == 0 || !h_start || !h_len || !h_stream_off) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && e->p.bits_per_sample > 16) return FLACAMD_E_INVALID_ARGUMENT;
+	if((uint64_t)nclips * FLACAMD_STREAM_HEAD_BYTES > 0xffffffffull) return FLACAMD_E_CAPACITY;   // the per-frame shift is 32 bits
+	const uint32_t N = e->cfg.N;
+	uint64_t F64 = 0;
+	int rc = streams_frames(e, nclips, h_start, h_len, &F64);
+	if(rc != FLACAMD_OK) return rc;
+	hipStream_t st = (hipStream_t)stream;
+	HIP_TRY(hipSetDevice(e->device));
+	if(!e->md5s) {
+		HIP_TRY(hipStreamCreateWithFlags(&e->md5s, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_md5, hipEventDisableTiming));
+	}
+	// host staging: frame_len[F] frame_num[F] frame_shift[F] | starts[n] ends[n] (u64) first[n] nframes[n] (u32) | stream_off[n + 1] (coming back)
+	const size_t F = (size_t)F64, n = nclips;
+	const size_t o_clip = (3u * F * 4u + 7u) & ~(size_t)7u, clip_bytes = n * (8u + 8u + 4u + 4u), o_back = o_clip + ((clip_bytes + 7u) & ~(size_t)7u);
+	const size_t d_dig_off = (clip_bytes + 15u) & ~(size_t)15u, d_soff = d_dig_off + n * 16u;
+	rc = tab_reserve(e, o_back + (n + 1u) * 8u, d_soff + (n + 1u) * 8u);
+	if(rc != FLACAMD_OK) return rc;
+	uint8_t *hb = (uint8_t*)e->h_tab;
+	uint32_t *flen = (uint32_t*)hb, *fnum = flen + F, *fshift = fnum + F;
+	uint64_t *cs = (uint64_t*)(hb + o_clip), *ce = cs + n; uint32_t *cf = (uint32_t*)(ce + n), *cn = cf + n;
+	{
+		uint32_t f = 0;
+		for(uint32_t i = 0; i < nclips; i++) {
+			const uint64_t nf = (h_len[i] + N - 1) / N;
+			cs[i] = h_start[i]; ce[i] = h_start[i] + h_len[i]; cf[i] = f; cn[i] = (uint32_t)nf;
+			for(uint64_t k = 0; k < nf; k++, f++) {
+				flen[f] = (k + 1 == nf) ? (uint32_t)(h_len[i] - k * N) : N;
+				fnum[f] = (uint32_t)k;
+				fshift[f] = (uint32_t)FLACAMD_STREAM_HEAD_BYTES * (i + 1u);
+			}
+		}
+	}
+	uint8_t *db = (uint8_t*)e->d_tab;
+	const uint64_t *d_cs = (const uint64_t*)db, *d_ce = d_cs + n; const uint32_t *d_cf = (const uint32_t*)(d_ce + n), *d_cn = d_cf + n;
+	uint8_t *d_dig = db + d_dig_off; uint64_t *d_so = (uint64_t*)(db + d_soff);
+	HIP_TRY(hipMemcpyAsync(e->work.frame_len, flen, F * 4u, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->work.frame_num, fnum, F * 4u, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(e->work.frame_shift, fshift, F * 4u, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(db, hb + o_clip, clip_bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipEventRecord(e->ev_tab, st));
+	// the digests: one lane per clip, a serial chain as long as the clip (md5.c:394-420); beside the coding stages
+	HIP_TRY(hipStreamWaitEvent(e->md5s, e->ev_tab, 0));
+	fa_launch_md5(d_pcm, (uint32_t)pcm_format, e->cfg.channels, e->cfg.bps, d_cs, d_ce, nclips, d_dig, e->md5s);
+	HIP_TRY(hipEventRecord(e->ev_md5, e->md5s));
+
+	FaCfg c = e->cfg;
+	c.pcm_format = (uint32_t)pcm_format;
+	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
+	c.last_n = N; c.last_fractional = 0; c.first_frame = 0; c.prev_assignment = 0;
+	c.multi = 2; c.skip_full = 0;
+	uint64_t total = 0;
+	rc = run_batch(e, c, d_pcm, d_out, out_cap, 0, &total, st);
+	const uint64_t need = total + (uint64_t)FLACAMD_STREAM_HEAD_BYTES * nclips;
+	if(h_total_bytes) *h_total_bytes = need;
+	if(rc != FLACAMD_OK) { (void)hipStreamSynchronize(e->md5s); return rc; }
+	HIP_TRY(hipStreamWaitEvent(st, e->ev_md5, 0));
+	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
+	hipLaunchKernelGGL(fa_clip_heads_kernel, dim3(nclips), dim3(64), 0, st, c, e->work, d_cs, d_ce, d_cf, d_cn, nclips, (const uint8_t*)d_dig, (uint8_t*)d_out, (unsigned long long)out_cap, d_so);
+	HIP_TRY(hipGetLastError());
+	uint32_t status = 0;
+	HIP_TRY(hipMemcpyAsync(hb + o_back, d_so, (n + 1u) * 8u, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&status, e->work.status, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if(status & 2u) return FLACAMD_E_CAPACITY;
+	memcpy(h_stream_off, hb + o_back, (n + 1u) * 8u);
+	return FLACAMD_OK;
 }
 
 extern "C" int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,

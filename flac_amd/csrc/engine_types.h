@@ -29,7 +29,7 @@ struct FaCfg {
 	uint32_t F;               // frames in this batch
 	uint32_t last_n;          // samples in the last frame of the batch
 	uint32_t last_fractional; // last frame is the short final block of the stream
-	uint32_t multi;           // the batch holds several complete streams: frame lengths and numbers come from FaWork::frame_len / frame_num
+	uint32_t multi;           // the batch holds several complete streams: frame lengths and numbers come from FaWork::frame_len / frame_num; 2 = each stream's frames are also moved FaWork::frame_shift bytes further in the output (room for the stream heads)
 	uint32_t skip_full;       // general search kernel: full-length frames are left to the register-resident kernel
 	uint32_t spill;           // blocks above FA_LDS_BLOCKSIZE samples: the general kernels keep their copy of the signal in FaWork::xs_spill instead of LDS
 	uint32_t first_frame;     // frame number of frame 0 of the batch
@@ -119,6 +119,7 @@ struct FaWork {
 	uint64_t *offsets;     // [F+1] exclusive scan of frame_bytes
 	uint32_t *frame_len;   // [F] samples per frame, multi-stream batches only
 	uint32_t *frame_num;   // [F] frame number within its stream, multi-stream batches only
+	uint32_t *frame_shift; // [F] bytes added to the frame's output offset (FaCfg::multi == 2)
 	int32_t  *xs_spill;    // [G][xs_words_for(N)] signal copies of the general kernels when FaCfg::spill (else unused)
 	const float *window;   // [num_apod][N]
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)

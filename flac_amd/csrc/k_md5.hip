@@ -75,11 +75,11 @@ __device__ __forceinline__ void md5_super_block(uint32_t (&h)[4], const void *pc
 }
 
 __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
-	const uint64_t *__restrict__ offsets, uint32_t nstreams, uint8_t *__restrict__ digests)
+	const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends, uint32_t nstreams, uint8_t *__restrict__ digests)
 {
 	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
 	if(sidx >= nstreams) return;
-	const uint64_t s0 = offsets[sidx], s1 = offsets[sidx + 1];
+	const uint64_t s0 = starts[sidx], s1 = ends[sidx];
 	const uint32_t nb = (bps + 7u) / 8u;
 	uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
 	// bulk: 64 values at a time are a whole number of blocks
@@ -136,7 +136,7 @@ extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format,
 	int rc = FLACAMD_OK;
 	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	if(rc == FLACAMD_OK) {
-		hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, nstreams, d_dig);
+		hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
 		if(hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 		if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	}
@@ -188,9 +188,16 @@ extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_
 	// nothing in the array has to start at zero: the kernel reads offsets[0..nstreams] and writes every byte of
 	// digests[0..nstreams), both overwritten here, and nothing beyond them is copied out
 	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
-	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, nstreams, d_dig);
+	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
 	int rc = hipGetLastError() == hipSuccess ? FLACAMD_OK : FLACAMD_E_DEVICE;
 	if(rc == FLACAMD_OK && hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	return rc;
+}
+
+// for the clip batch entry point of engine.hip: streams [starts[i], ends[i]) of d_pcm, digests to device memory, no synchronisation
+extern "C" void fa_launch_md5(const void *d_pcm, uint32_t pcm_format, uint32_t channels, uint32_t bits_per_sample, const uint64_t *d_starts, const uint64_t *d_ends,
+	uint32_t nstreams, uint8_t *d_digests, hipStream_t st)
+{
+	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, pcm_format, channels, bits_per_sample, d_starts, d_ends, nstreams, d_digests);
 }

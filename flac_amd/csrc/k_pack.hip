@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(256) fa_gather_kernel(FaCfg c, FaWork w, uint8
 {
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
 	const uint32_t nb = w.frame_bytes[f];
-	const unsigned long long off = w.offsets[f];
+	const unsigned long long off = w.offsets[f] + (c.multi == 2u ? w.frame_shift[f] : 0u);
 	if(tid == 0 && frame_bytes_out) frame_bytes_out[f] = nb;
 	if(off + nb > out_cap) { if(tid == 0) atomicOr(w.status, 2u); return; }
 	const uint8_t *src = w.slots + (size_t)f * c.slot_bytes;

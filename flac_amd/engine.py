@@ -69,6 +69,7 @@ def lib():
         L.flacamd_encoder_max_output_bytes.restype = sz
         L.flacamd_encode_device.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), vp]
         L.flacamd_encode_streams_device.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp, sz, vp, C.POINTER(u64), vp]
+        L.flacamd_encode_clips_device.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp, sz, vp, C.POINTER(u64), vp]
         L.flacamd_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), C.POINTER(u32)]
         L.flacamd_encoder_debug_read.argtypes = [vp, C.c_int, vp, sz]
         L.flacamd_encoder_debug_read.restype = C.c_long
@@ -225,6 +226,20 @@ class Encoder:
             raise OutputTooSmall(int(total.value))   # frames beyond the verbatim bound: call again with that many bytes
         _check(rc, "flacamd_encode_streams_device")
         return int(total.value)
+
+    def encode_clips_device(self, d_pcm_ptr, fmt, starts, lengths, d_out_ptr, out_cap, stream=None):
+        """A batch of clips as complete streams assembled on the device (flacamd_encode_clips_device).  Returns the
+        byte offsets of the streams within the output (len(starts) + 1 entries)."""
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        offs = np.zeros(len(st) + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        rc = self._lib.flacamd_encode_clips_device(self._h, d_pcm_ptr, fmt, len(st), st.ctypes.data, ln.ctypes.data, d_out_ptr, out_cap,
+                                                   offs.ctypes.data, C.byref(total), stream)
+        if rc == -6 and total.value > out_cap:
+            raise OutputTooSmall(int(total.value))
+        _check(rc, "flacamd_encode_clips_device")
+        return offs
 
     def debug(self, what, dtype, count):
         buf = np.empty(count, dtype=dtype)

@@ -132,6 +132,17 @@ int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_pcm, int pcm
 	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint32_t *d_frame_bytes,
 	uint64_t *h_total_bytes, void *stream);
 
+/* A batch of clips as COMPLETE streams in one pass: like flacamd_encode_streams_device, but every clip comes out as the
+ * file the reference's encoder leaves behind for it when given a seekable sink and no client metadata - "fLaC",
+ * STREAMINFO with frame size extremes, sample count and the MD5 of its samples (stream_encoder.c:1034-1106, :2521-2620;
+ * md5.c:394-420, one GPU lane per clip beside the coding stages), the VORBIS_COMMENT carrying the vendor string, then
+ * its frames.  The streams lie back to back in d_out; h_stream_off[nclips + 1] receives their byte offsets.  With
+ * FLACAMD_E_CAPACITY, *h_total_bytes is the output size the call needs.  No counterpart in the reference (one encoder
+ * object per stream there); replaces the per-file loop of the flac tool (src/flac/main.c:327, encode.c:966) for clips
+ * already in device memory. */
+int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nclips,
+	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint64_t *h_stream_off, uint64_t *h_total_bytes, void *stream);
+
 /* Same with host buffers: copies PCM in, frames and sizes out (PCIe inclusive). */
 int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
