@@ -34,6 +34,7 @@ struct FdCfg {
 	uint32_t pcm_format;
 	uint32_t debug;       // development ablation switches (FLACAMD_DECODE_DEBUG), 0 in production
 	uint32_t tolerant;    // CRC-valid frames that do not follow one another are still written out (the caller sorts out the damage)
+	uint32_t subinfo;     // the parser also records what it read of every subframe (FdWork::subinfo)
 	uint64_t pcm_cap;
 };
 
@@ -53,6 +54,7 @@ struct FdWork {
 	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
 	const uint16_t *crc_tab;   // [4][256] CRC-16 of a byte followed by 0..3 zero bytes
 	const uint16_t *crc_segmul;// [256] x^(8 * crc_seg_bytes * j)
+	flacamd_subframe_info *subinfo; // [max_frames][channels] when FdCfg::subinfo, by candidate
 };
 
 // ---- header parsing shared by the scan and the decode kernels
@@ -373,6 +375,8 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 		for(uint32_t ch = 0; ch < c.channels; ch++) {
 			// ---- head of the subframe (per lane, no barrier inside)
 			uint32_t bps = h.bps, wasted = 0, order = 0, type = 0, nres = 0, po = 0, plen = 4, esc = 15;
+			// what the reference keeps in FLAC__Subframe for the client (stream_decoder.c:2456-2719), when asked for
+			flacamd_subframe_info *const sub = (c.subinfo && live) ? w.subinfo + ((size_t)ci * c.channels + ch) : (flacamd_subframe_info*)0;
 			if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
 			if(ok) do {
 				uint32_t head = br.read(8);
@@ -381,29 +385,31 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				head &= 0xfeu;
 				if(!(head == 0 || head == 2 || (head >= 16 && head <= 24) || head >= 64)) { ex = 4; ok = false; break; }   // reserved subframe types :2494, :2505
 				if(wasted) { if(wasted >= bps) { ex = 5; ok = false; break; } bps -= wasted; }
-				if(head == 0) { type = 0; push((int32_t)(0u | (wasted << 8))); push(1); push(br.read_signed(bps)); break; }   // constant :2526
-				if(head == 2) { type = 1; nres = n; push((int32_t)(1u | (wasted << 8))); push((int32_t)n); break; }            // verbatim :2698
+				if(head == 0) { type = 0; push((int32_t)(0u | (wasted << 8))); push(1); const int32_t cv = br.read_signed(bps); push(cv); if(sub) { sub->head = wasted << 8; sub->value = cv; } break; }   // constant :2526
+				if(head == 2) { type = 1; nres = n; push((int32_t)(1u | (wasted << 8))); push((int32_t)n); if(sub) sub->head = 1u | (wasted << 8); break; }            // verbatim :2698
 				const bool lpc = head >= 64;
 				type = lpc ? 3u : 2u;
 				order = lpc ? ((head >> 1) & 31u) + 1u : (head >> 1) & 7u;
 				if(!lpc && order > 4u) { ex = 4; ok = false; break; }                          // :2494-2508 (reserved type codes)
 				push((int32_t)(type | (order << 2) | (wasted << 8)));
-				for(uint32_t i = 0; i < order; i++) { br.top_up(); push(br.read_signed(bps)); }
-				uint32_t shift = 0, wide = 0;
+				for(uint32_t i = 0; i < order; i++) { br.top_up(); const int32_t wv = br.read_signed(bps); push(wv); if(sub) sub->warmup[i] = wv; }
+				uint32_t shift = 0, wide = 0, prec_read = 0, shift_read = 0;
 				if(lpc) {
 					uint32_t prec = br.read(4);
 					if(prec == 15u) { ex = 1; ok = false; break; }                           // :2628
 					prec++;
 					const int32_t sh = br.read_signed(5);
+					prec_read = prec; shift_read = (uint32_t)sh & 31u;
 					// a negative shift is never produced by the reference encoder (lpc.c:225-260) and shifting by it is undefined
 					// there; the frame still parses the same way, so go on for the sake of its length
 					shift = sh < 0 ? 0u : (uint32_t)sh;
-					for(uint32_t j = 0; j < order; j++) { br.top_up(); s_q[j][lane] = (int16_t)br.read_signed(prec); }
+					for(uint32_t j = 0; j < order; j++) { br.top_up(); const int16_t qv = (int16_t)br.read_signed(prec); s_q[j][lane] = qv; if(sub) sub->q[j] = qv; }
 					wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
 				}
 				const uint32_t method = br.read(2);
 				if(method > 1u) { ex = 4; ok = false; break; }                               // :2580
 				po = br.read(4); plen = method ? 5u : 4u; esc = method ? 31u : 15u;
+				if(sub) sub->head = type | (order << 2) | (wasted << 8) | (prec_read << 13) | (method << 18) | (po << 19) | (shift_read << 23);
 				if(po == 0) { if(n < order) { ex = 1; ok = false; break; } } else if((n >> po) < order) { ex = 1; ok = false; break; } // :2732-2745
 				// a blocksize that the partition count does not divide: the reference reads (n >> po) samples per partition
 				// all the same (:2727) and leaves the rest of the block undefined
@@ -450,6 +456,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						           : ((fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW);
 						left = hdr ? left_h : left;
 						k = hdr ? kh : k;
+						if(sub && hdr && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh;
 						part += hdr ? 1u : 0u;
 					}
 					else if(mode == M_LOW) {
@@ -458,7 +465,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
 						take = k; qacc = 0; have = true; mode = M_TOKEN;
 					}
-					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; r = 0; have = false; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; }
+					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; r = 0; have = false; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; if(sub && part - 1u < FLACAMD_SUBINFO_PARTS) sub->rice[part - 1u] = (uint8_t)(0x80u | raw); }
 					else if(mode == M_RAW) { r = raw ? (int32_t)hi >> (32u - raw) : 0; take = raw; have = true; }
 					else { r = (int32_t)hi >> (32u - bps); take = bps; have = true; }   // verbatim sample
 					br.buf <<= take; br.avail -= take;
@@ -472,7 +479,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				if((it & (FD_K - 1u)) == FD_K - 1u && !(c.debug & 8u)) hand_over(false);
 			}
 			hand_over(false);
-			if(ok && type >= 2u && part == 0) { const uint32_t k0 = br.read(plen); if(k0 >= esc) (void)br.read(5); }   // order == blocksize: the one partition is empty, its header is still there
+			if(ok && type >= 2u && part == 0) { const uint32_t k0 = br.read(plen); uint32_t rb = 0; if(k0 >= esc) rb = 0x80u | br.read(5); if(sub) sub->rice[0] = (uint8_t)(rb ? rb : k0); }   // order == blocksize: the one partition is empty, its header is still there
 			if(ok && (br.err || br.bitpos() > c.nbytes * 8u)) ok = false;
 		}
 		hand_over(true);
@@ -757,6 +764,7 @@ struct flacamd_decoder {
 	size_t max_bytes;
 	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
 	uint32_t last_ncand, last_nframes, last_damage;
+	void *d_subinfo;
 };
 
 #define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
@@ -815,6 +823,7 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	if(d->arena) (void)hipFree(d->arena);
 	if(d->d_in_stage) (void)hipFree(d->d_in_stage);
 	if(d->d_pcm_stage) (void)hipFree(d->d_pcm_stage);
+	if(d->d_subinfo) (void)hipFree(d->d_subinfo);
 	free(d);
 }
 
@@ -943,5 +952,28 @@ extern "C" int flacamd_decoder_candidate_table(flacamd_decoder *d, uint32_t max_
 		free(fo); free(so);
 		if(rc != FLACAMD_OK) return rc;
 	}
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_set_subframe_info(flacamd_decoder *d, int on)
+{
+	if(!d) return FLACAMD_E_INVALID_ARGUMENT;
+	if(on && !d->d_subinfo) {
+		FD_TRY(hipSetDevice(d->device));
+		FD_TRY(hipMalloc(&d->d_subinfo, (size_t)d->cfg.max_frames * d->cfg.channels * sizeof(flacamd_subframe_info)));
+		d->work.subinfo = (flacamd_subframe_info*)d->d_subinfo;
+	}
+	d->cfg.subinfo = on ? 1u : 0u;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_subframe_info(flacamd_decoder *d, uint32_t max_candidates, flacamd_subframe_info *h_records, uint32_t *h_frame_candidate, uint32_t max_frames)
+{
+	if(!d || !h_records || !d->cfg.subinfo || !d->d_subinfo) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t nc = d->last_ncand, nf = d->last_nframes;
+	if(nc > max_candidates || (h_frame_candidate && nf > max_frames)) return FLACAMD_E_CAPACITY;
+	FD_TRY(hipSetDevice(d->device));
+	if(nc) FD_TRY(hipMemcpy(h_records, d->d_subinfo, (size_t)nc * d->cfg.channels * sizeof(flacamd_subframe_info), hipMemcpyDeviceToHost));
+	if(h_frame_candidate && nf) FD_TRY(hipMemcpy(h_frame_candidate, d->work.frame_of, (size_t)nf * 4u, hipMemcpyDeviceToHost));
 	return FLACAMD_OK;
 }

@@ -27,6 +27,10 @@ const char * const FLAC__StreamDecoderErrorStatusString[] = { /* :162-167 */
 	"FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC", "FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER", "FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH",
 	"FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM" };
 
+const char * const FLAC__SubframeTypeString[] = { "CONSTANT", "VERBATIM", "FIXED", "LPC" };                       /* format.c:160-165 */
+const char * const FLAC__EntropyCodingMethodTypeString[] = { "PARTITIONED_RICE", "PARTITIONED_RICE2" };             /* format.c:143-146 */
+const char * const FLAC__ChannelAssignmentString[] = { "INDEPENDENT", "LEFT_SIDE", "RIGHT_SIDE", "MID_SIDE" };      /* format.c:167-172 */
+
 struct FLAC__StreamDecoder {
 	FLAC__StreamDecoderState state;
 	FLAC__bool md5_checking, do_md5;
@@ -49,6 +53,10 @@ struct FLAC__StreamDecoder {
 	 * walk over damaged input took it, else all ones = the running count */
 	uint64_t *f_off, *f_num, *f_end, *f_sn; uint32_t *f_bs, *f_asg; uint8_t *f_kind; unsigned q_n, q_i, ev_cap; FLAC__uint64 batch_base;
 	uint64_t *c_pos, *c_end, *c_num, *c_off; uint32_t *c_info, *c_bs;   /* candidate table of a damaged batch */
+	/* what the device read of every subframe of the batch (by candidate), and per queued event its candidate; the
+	 * per-channel parameter arrays FLAC__Frame.subframes[] point at (include/FLAC/format.h:213-240) */
+	flacamd_subframe_info *sub; uint32_t *f_cand, *frame_cand; size_t batch_in_off;
+	FLAC__EntropyCodingMethod_PartitionedRiceContents prc[8]; unsigned prc_alloc[8];
 	int search_warned;               /* LOST_SYNC already reported for the sync search in progress (frame_sync_'s `first`) */
 	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
 	int32_t *planar; uint8_t *md5_scratch;
@@ -81,6 +89,8 @@ static void dec_free(FLAC__StreamDecoder *d)
 	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
 	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
 	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
+	free(d->sub); d->sub = 0; free(d->f_cand); d->f_cand = 0; free(d->frame_cand); d->frame_cand = 0;
+	{ unsigned c; for(c = 0; c < 8; c++) { free(d->prc[c].parameters); free(d->prc[c].raw_bits); d->prc[c].parameters = d->prc[c].raw_bits = 0; d->prc_alloc[c] = 0; } }
 }
 
 void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
@@ -324,7 +334,11 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 			d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0;
 		}
 		(void)flacamd_decoder_set_tolerant(d->eng, 1);
+		if(flacamd_decoder_set_subframe_info(d->eng, 1) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->ev_cap = 4u * d->eng_frames + 64u;
+		d->sub = (flacamd_subframe_info*)malloc(sizeof(flacamd_subframe_info) * (size_t)d->eng_frames * si->channels);
+		d->f_cand = (uint32_t*)malloc(4u * d->ev_cap); d->frame_cand = (uint32_t*)malloc(4u * d->eng_frames);
+		if(!d->sub || !d->f_cand || !d->frame_cand) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->pcm = (int32_t*)malloc(sizeof(int32_t) * d->pcm_cap * si->channels);
 		d->f_off = (uint64_t*)malloc(8u * d->ev_cap); d->f_num = (uint64_t*)malloc(8u * d->ev_cap); d->f_end = (uint64_t*)malloc(8u * d->ev_cap); d->f_sn = (uint64_t*)malloc(8u * d->ev_cap);
 		d->f_bs = (uint32_t*)malloc(4u * d->ev_cap); d->f_asg = (uint32_t*)malloc(4u * d->ev_cap); d->f_kind = (uint8_t*)malloc(d->ev_cap);
@@ -397,9 +411,12 @@ static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
  * what the client has to see, in order: error reports, frames, and zeroed frames for CRC failures. */
 enum { EV_FRAME = 0, EV_ZERO_FRAME = 1, EV_ERROR = 2, EV_END = 3, EV_END_FAIL = 4, EV_ABORT = 5 };
 
-static void push_event(FLAC__StreamDecoder *d, unsigned kind, unsigned status_or_asg, unsigned bs, uint64_t off, uint64_t sn, uint64_t end)
+static void push_event_c(FLAC__StreamDecoder *d, unsigned kind, unsigned status_or_asg, unsigned bs, uint64_t off, uint64_t sn, uint64_t end, uint32_t cand);
+static void push_event(FLAC__StreamDecoder *d, unsigned kind, unsigned status_or_asg, unsigned bs, uint64_t off, uint64_t sn, uint64_t end) { push_event_c(d, kind, status_or_asg, bs, off, sn, end, 0); }
+static void push_event_c(FLAC__StreamDecoder *d, unsigned kind, unsigned status_or_asg, unsigned bs, uint64_t off, uint64_t sn, uint64_t end, uint32_t cand)
 {
 	const unsigned r = d->q_n++;
+	d->f_cand[r] = cand; d->f_num[r] = 0;
 	d->f_kind[r] = (uint8_t)kind; d->f_asg[r] = status_or_asg; d->f_bs[r] = bs; d->f_off[r] = off; d->f_sn[r] = sn; d->f_end[r] = end; d->f_num[r] = 0;
 }
 
@@ -504,10 +521,10 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 				const uint32_t bs = d->c_bs[ci];
 				const int variable = (b[s + 1] & 1) || si->min_blocksize != si->max_blocksize;
 				const uint64_t sn = variable ? d->c_num[ci] : d->c_num[ci] * (uint64_t)si->min_blocksize; /* :2422-2445 */
-				if((info & 2u) && d->c_off[ci] != ~(uint64_t)0) push_event(d, EV_FRAME, (info >> 4) & 15u, bs, d->c_off[ci], sn, end);
+				if((info & 2u) && d->c_off[ci] != ~(uint64_t)0) { push_event_c(d, EV_FRAME, (info >> 4) & 15u, bs, d->c_off[ci], sn, end, ci); d->f_num[d->q_n - 1] = s; }
 				else { /* :2111-2119 */
 					push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, 0, 0, 0, end);
-					push_event(d, EV_ZERO_FRAME, (info >> 4) & 15u, bs, 0, sn, end);
+					push_event_c(d, EV_ZERO_FRAME, (info >> 4) & 15u, bs, 0, sn, end, ci); d->f_num[d->q_n - 1] = s;
 				}
 				sd = sn + bs; pos = (size_t)end;
 			}
@@ -531,7 +548,8 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		break;
 	}
 	if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
-	d->batch_base = d->in_base + d->in_pos;
+	d->batch_base = d->in_base + d->in_pos; d->batch_in_off = d->in_pos;
+	if(flacamd_decoder_subframe_info(d->eng, d->eng_frames, d->sub, d->frame_cand, d->eng_frames) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
 	if(flacamd_decoder_damage(d->eng) == 0) {
 		const uint8_t *b = d->in + d->in_pos;
 		if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, d->c_pos, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
@@ -539,6 +557,7 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		for(r = 0; r < d->q_n; r++) { /* the sample number as read_frame_header_ derives it (:2346-2376, :2422-2445) */
 			const int variable = (b[d->c_pos[r] + 1] & 1) || si->min_blocksize != si->max_blocksize;
 			d->f_kind[r] = EV_FRAME; d->f_sn[r] = variable ? d->f_num[r] : d->f_num[r] * (uint64_t)si->min_blocksize;
+			d->f_cand[r] = d->frame_cand[r]; d->f_num[r] = d->c_pos[r];   /* from here on: where the frame starts in the batch */
 		}
 		d->search_warned = 0;
 		d->in_pos += (size_t)info[3];
@@ -551,6 +570,58 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		d->in_pos += used;
 	}
 	return 1;
+}
+
+/* the sample rate out of the frame's own header bytes, and the subframe records of its candidate */
+static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const uint8_t *fb, size_t flen, uint32_t cand)
+{
+	static const unsigned rates[12] = { 0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000 };
+	const unsigned ch = frame->header.channels; unsigned c;
+	if(flen >= 8) {
+		const unsigned bs_code = fb[2] >> 4, sr_code = fb[2] & 15u; const uint8_t x = fb[4];
+		size_t p = 5 + (!(x & 0x80) ? 0u : !(x & 0x20) ? 1u : !(x & 0x10) ? 2u : !(x & 0x08) ? 3u : !(x & 0x04) ? 4u : !(x & 0x02) ? 5u : 6u);
+		if(bs_code == 6) p += 1; else if(bs_code == 7) p += 2;
+		if(sr_code && sr_code < 12) frame->header.sample_rate = rates[sr_code];
+		else if(sr_code == 12 && p < flen) { frame->header.sample_rate = fb[p] * 1000u; p += 1; }
+		else if((sr_code == 13 || sr_code == 14) && p + 1 < flen) { frame->header.sample_rate = (((unsigned)fb[p] << 8) | fb[p + 1]) * (sr_code == 14 ? 10u : 1u); p += 2; }
+		/* header.crc and footer.crc stay 0: the reference's decoder checks both CRCs but never stores them in the frame it hands out */
+	}
+	for(c = 0; c < ch && c < 8; c++) {
+		const flacamd_subframe_info *rec = &d->sub[(size_t)cand * ch + c];
+		FLAC__Subframe *sf = &frame->subframes[c];
+		const unsigned type = rec->head & 3u, order = (rec->head >> 2) & 63u, po = (rec->head >> 19) & 15u; unsigned i;
+		FLAC__EntropyCodingMethod *ecm = 0;
+		sf->type = (FLAC__SubframeType)type; sf->wasted_bits = (rec->head >> 8) & 31u;
+		if(type == FLAC__SUBFRAME_TYPE_CONSTANT) sf->data.constant.value = rec->value;
+		else if(type == FLAC__SUBFRAME_TYPE_FIXED) {
+			sf->data.fixed.order = order; sf->data.fixed.residual = 0; ecm = &sf->data.fixed.entropy_coding_method;
+			for(i = 0; i < order && i < FLAC__MAX_FIXED_ORDER; i++) sf->data.fixed.warmup[i] = rec->warmup[i];
+		}
+		else if(type == FLAC__SUBFRAME_TYPE_LPC) {
+			const unsigned lv = (rec->head >> 23) & 31u;
+			sf->data.lpc.order = order; sf->data.lpc.residual = 0; ecm = &sf->data.lpc.entropy_coding_method;
+			sf->data.lpc.qlp_coeff_precision = (rec->head >> 13) & 31u;
+			sf->data.lpc.quantization_level = (lv & 16u) ? (int)lv - 32 : (int)lv;
+			for(i = 0; i < order && i < FLAC__MAX_LPC_ORDER; i++) { sf->data.lpc.qlp_coeff[i] = rec->q[i]; sf->data.lpc.warmup[i] = rec->warmup[i]; }
+		}
+		if(ecm) {
+			const unsigned rice2 = (rec->head >> 18) & 1u, escape = rice2 ? 31u : 15u, cap = po > 8 ? po : 8u;
+			FLAC__EntropyCodingMethod_PartitionedRiceContents *pc = &d->prc[c];
+			if(d->prc_alloc[c] < cap || !pc->parameters) {
+				unsigned *np = (unsigned*)realloc(pc->parameters, sizeof(unsigned) << cap), *nr = (unsigned*)realloc(pc->raw_bits, sizeof(unsigned) << cap);
+				if(np) pc->parameters = np;
+				if(nr) pc->raw_bits = nr;
+				if(!np || !nr) { ecm->data.partitioned_rice.contents = 0; ecm->data.partitioned_rice.order = po; continue; }
+				d->prc_alloc[c] = cap; pc->capacity_by_order = cap;
+			}
+			for(i = 0; i < (1u << po); i++) {
+				const unsigned v = i < FLACAMD_SUBINFO_PARTS ? rec->rice[i] : 0u;
+				if(v & 0x80u) { pc->parameters[i] = escape; pc->raw_bits[i] = v & 31u; } else { pc->parameters[i] = v; pc->raw_bits[i] = 0; }
+			}
+			ecm->type = rice2 ? FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 : FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE;
+			ecm->data.partitioned_rice.order = po; ecm->data.partitioned_rice.contents = pc;
+		}
+	}
 }
 
 /* the next frame of the stream: error reports on the way, then write_audio_frame_to_client_ (:2915-2990) */
@@ -580,6 +651,10 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	frame.header.channel_assignment = (FLAC__ChannelAssignment)d->f_asg[r]; frame.header.bits_per_sample = si->bits_per_sample;
 	frame.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
 	frame.header.number.sample_number = d->samples_decoded; /* frame number x fixed blocksize for the streams this decoder takes (:2422-2445) */
+	{ /* what read_frame_header_ / read_subframe_* leave in the frame (:2147-2454, :2456-2719) */
+		const uint8_t *fb = d->in + d->batch_in_off + d->f_num[r]; const size_t flen = (size_t)(d->f_end[r] - d->f_num[r]);
+		fill_frame_details(d, &frame, fb, flen, d->f_cand[r]);
+	}
 	d->last = frame.header;
 	if(d->do_md5 && deliver) {
 		if(src) md5_feed_pcm(&d->md5, src, (size_t)n * ch, si->bits_per_sample, d->md5_scratch, 65536);
@@ -604,6 +679,7 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 		else memset(dst, 0, sizeof(int32_t) * n);
 		bufs[c] = dst;
 	}
+	for(c = 0; c < ch; c++) if(frame.subframes[c].type == FLAC__SUBFRAME_TYPE_VERBATIM) frame.subframes[c].data.verbatim.data = bufs[c];
 	if(d->write_cb(d, &frame, bufs, d->client_data) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
 	return 1;
 }

@@ -444,8 +444,58 @@ class FrameHeader(C.Structure):
                 ("bits_per_sample", C.c_uint), ("number_type", C.c_int), ("number", _FrameNumber), ("crc", C.c_uint8)]
 
 
+class RiceContents(C.Structure):
+    _fields_ = [("parameters", C.POINTER(C.c_uint)), ("raw_bits", C.POINTER(C.c_uint)), ("capacity_by_order", C.c_uint)]
+
+
+class PartitionedRice(C.Structure):
+    _fields_ = [("order", C.c_uint), ("contents", C.POINTER(RiceContents))]
+
+
+class EntropyCodingMethod(C.Structure):
+    _fields_ = [("type", C.c_int), ("partitioned_rice", PartitionedRice)]
+
+
+class SubframeFixed(C.Structure):
+    _fields_ = [("entropy_coding_method", EntropyCodingMethod), ("order", C.c_uint), ("warmup", C.c_int32 * 4), ("residual", C.POINTER(C.c_int32))]
+
+
+class SubframeLPC(C.Structure):
+    _fields_ = [("entropy_coding_method", EntropyCodingMethod), ("order", C.c_uint), ("qlp_coeff_precision", C.c_uint), ("quantization_level", C.c_int),
+                ("qlp_coeff", C.c_int32 * 32), ("warmup", C.c_int32 * 32), ("residual", C.POINTER(C.c_int32))]
+
+
+class _SubframeData(C.Union):
+    _fields_ = [("constant", C.c_int32), ("fixed", SubframeFixed), ("lpc", SubframeLPC), ("verbatim", C.POINTER(C.c_int32))]
+
+
+class Subframe(C.Structure):
+    _fields_ = [("type", C.c_int), ("data", _SubframeData), ("wasted_bits", C.c_uint)]
+
+
 class Frame(C.Structure):
-    _fields_ = [("header", FrameHeader), ("footer_crc", C.c_uint16)]
+    """FLAC__Frame (include/FLAC/format.h:472-476)"""
+    _fields_ = [("header", FrameHeader), ("subframes", Subframe * 8), ("footer_crc", C.c_uint16)]
+
+
+def subframe_summary(frame):
+    """The analysis view of a decoded frame (what src/flac/analyze.c prints): one dict per channel."""
+    out = []
+    for c in range(frame.header.channels):
+        sf = frame.subframes[c]
+        d = dict(type=int(sf.type), wasted_bits=int(sf.wasted_bits))
+        body = sf.data.fixed if sf.type == 2 else sf.data.lpc if sf.type == 3 else None
+        if sf.type == 0:
+            d["value"] = int(sf.data.constant)
+        if body is not None:
+            po = int(body.entropy_coding_method.partitioned_rice.order)
+            pc = body.entropy_coding_method.partitioned_rice.contents.contents
+            d.update(order=int(body.order), warmup=[int(body.warmup[i]) for i in range(body.order)], method=int(body.entropy_coding_method.type), partition_order=po,
+                     parameters=[int(pc.parameters[i]) for i in range(1 << po)], raw_bits=[int(pc.raw_bits[i]) for i in range(1 << po)])
+            if sf.type == 3:
+                d.update(qlp_coeff_precision=int(body.qlp_coeff_precision), quantization_level=int(body.quantization_level), qlp_coeff=[int(body.qlp_coeff[i]) for i in range(body.order)])
+        out.append(d)
+    return out
 
 
 D_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t), C.c_void_p)

@@ -265,6 +265,27 @@ uint32_t flacamd_decoder_damage(const flacamd_decoder *d);
 int flacamd_decoder_candidate_table(flacamd_decoder *d, uint32_t max_entries, uint32_t *h_count, uint64_t *h_byte_pos, uint64_t *h_byte_end,
 	uint32_t *h_info, uint32_t *h_blocksize, uint64_t *h_number, uint64_t *h_sample_off);
 
+/* What the decoder read of one subframe: the fields the reference leaves in FLAC__Subframe for the client's write
+ * callback (include/FLAC/format.h:283-352, filled by read_subframe_* stream_decoder.c:2456-2719), for analysis clients
+ * (src/flac/analyze.c:61-125).  Recorded per candidate frame and channel when flacamd_decoder_set_subframe_info is on.
+ *   head: [1:0] type (0 constant, 1 verbatim, 2 fixed, 3 lpc)  [7:2] order  [12:8] wasted bits
+ *         [17:13] coefficient precision (lpc)  [18] residual coding method (0 RICE, 1 RICE2)  [22:19] partition order
+ *         [27:23] quantisation level as coded (5-bit two's complement)
+ *   value: the sample of a constant subframe (before the wasted-bits shift)
+ *   rice[i]: parameter of partition i, or 0x80 | raw_bits for an escaped partition; the first FLACAMD_SUBINFO_PARTS
+ *         partitions are recorded (partition orders up to 8, the streamable subset's limit) */
+#define FLACAMD_SUBINFO_PARTS 256u
+typedef struct {
+	uint32_t head; int32_t value; uint32_t reserved[2];
+	int32_t warmup[FLACAMD_MAX_LPC_ORDER];
+	int16_t q[FLACAMD_MAX_LPC_ORDER];
+	uint8_t rice[FLACAMD_SUBINFO_PARTS];
+} flacamd_subframe_info;
+int flacamd_decoder_set_subframe_info(flacamd_decoder *d, int on);
+/* The records of the last decode, by candidate (as in flacamd_decoder_candidate_table): h_records[candidate * channels
+ * + channel].  h_frame_candidate (may be NULL) receives, per accepted frame in stream order, its candidate index. */
+int flacamd_decoder_subframe_info(flacamd_decoder *d, uint32_t max_candidates, flacamd_subframe_info *h_records, uint32_t *h_frame_candidate, uint32_t max_frames);
+
 /* "fLaC" + STREAMINFO + the empty VORBIS_COMMENT with the reference's vendor string, as the reference
  * leaves them in a finished file (stream_encoder.c:1034-1106 written at init, :2521-2620 patched at
  * finish): for callers that assemble streams from engine output themselves.  Returns the byte count. */

@@ -31,6 +31,10 @@ typedef uint8_t FLAC__byte;
 typedef int32_t FLAC__int32;
 typedef uint32_t FLAC__uint32;
 typedef uint64_t FLAC__uint64;
+typedef uint8_t FLAC__uint8;
+typedef uint16_t FLAC__uint16;
+typedef int16_t FLAC__int16;
+typedef int64_t FLAC__int64;
 
 /* values and order of include/FLAC/stream_encoder.h:240-278 */
 typedef enum {
@@ -320,10 +324,70 @@ typedef struct {
 	unsigned bits_per_sample;
 	FLAC__FrameNumberType number_type;   /* always SAMPLE_NUMBER when handed to the client (stream_decoder.c:2422-2445) */
 	union { FLAC__uint32 frame_number; FLAC__uint64 sample_number; } number;
-	FLAC__byte crc;
+	FLAC__uint8 crc;
 } FLAC__FrameHeader;
-typedef struct { uint16_t crc; } FLAC__FrameFooter;
-typedef struct { FLAC__FrameHeader header; FLAC__FrameFooter footer; } FLAC__Frame;
+typedef struct { FLAC__uint16 crc; } FLAC__FrameFooter;
+
+/* include/FLAC/format.h:190-352: what the decoder tells the client about every subframe of a frame */
+#define FLAC__MAX_CHANNELS 8u
+#define FLAC__MAX_FIXED_ORDER 4u
+#define FLAC__MAX_LPC_ORDER 32u
+typedef enum { FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE = 0, FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 = 1 } FLAC__EntropyCodingMethodType;
+typedef struct {
+	unsigned *parameters;       /* the Rice parameter of each partition (the escape code for an escaped one) */
+	unsigned *raw_bits;         /* width of the samples of an escaped partition, 0 for the others */
+	unsigned capacity_by_order; /* the arrays hold 2^capacity_by_order entries */
+} FLAC__EntropyCodingMethod_PartitionedRiceContents;
+typedef struct {
+	unsigned order;
+	const FLAC__EntropyCodingMethod_PartitionedRiceContents *contents;
+} FLAC__EntropyCodingMethod_PartitionedRice;
+typedef struct {
+	FLAC__EntropyCodingMethodType type;
+	union { FLAC__EntropyCodingMethod_PartitionedRice partitioned_rice; } data;
+} FLAC__EntropyCodingMethod;
+typedef enum { FLAC__SUBFRAME_TYPE_CONSTANT = 0, FLAC__SUBFRAME_TYPE_VERBATIM = 1, FLAC__SUBFRAME_TYPE_FIXED = 2, FLAC__SUBFRAME_TYPE_LPC = 3 } FLAC__SubframeType;
+typedef struct { FLAC__int32 value; } FLAC__Subframe_Constant;
+typedef struct { const FLAC__int32 *data; } FLAC__Subframe_Verbatim;
+typedef struct {
+	FLAC__EntropyCodingMethod entropy_coding_method;
+	unsigned order;
+	FLAC__int32 warmup[FLAC__MAX_FIXED_ORDER];
+	const FLAC__int32 *residual;
+} FLAC__Subframe_Fixed;
+typedef struct {
+	FLAC__EntropyCodingMethod entropy_coding_method;
+	unsigned order;
+	unsigned qlp_coeff_precision;
+	int quantization_level;
+	FLAC__int32 qlp_coeff[FLAC__MAX_LPC_ORDER];
+	FLAC__int32 warmup[FLAC__MAX_LPC_ORDER];
+	const FLAC__int32 *residual;
+} FLAC__Subframe_LPC;
+typedef struct {
+	FLAC__SubframeType type;
+	union {
+		FLAC__Subframe_Constant constant;
+		FLAC__Subframe_Fixed fixed;
+		FLAC__Subframe_LPC lpc;
+		FLAC__Subframe_Verbatim verbatim;
+	} data;
+	unsigned wasted_bits;
+} FLAC__Subframe;
+extern const char * const FLAC__SubframeTypeString[];
+extern const char * const FLAC__EntropyCodingMethodTypeString[];
+extern const char * const FLAC__ChannelAssignmentString[];
+
+/* include/FLAC/format.h:472-476.  The decoder's write callback receives the frame as the reference's does, with two
+ * differences, both about samples this decoder never holds on the host: `residual` of FIXED / LPC subframes is NULL
+ * (the residual exists only on the device), and `data` of a VERBATIM subframe points at the channel's output samples
+ * (equal to the coded ones unless the subframe has wasted bits).  Of a partitioned-Rice residual with a partition
+ * order above 8 (outside the streamable subset) the first 256 parameters are filled in, the rest read 0. */
+typedef struct {
+	FLAC__FrameHeader header;
+	FLAC__Subframe subframes[FLAC__MAX_CHANNELS];
+	FLAC__FrameFooter footer;
+} FLAC__Frame;
 
 typedef struct FLAC__StreamDecoder FLAC__StreamDecoder;
 
