@@ -57,6 +57,12 @@ struct FLAC__StreamDecoder {
 	 * per-channel parameter arrays FLAC__Frame.subframes[] point at (include/FLAC/format.h:213-240) */
 	flacamd_subframe_info *sub; uint32_t *f_cand, *frame_cand; size_t batch_in_off;
 	FLAC__EntropyCodingMethod_PartitionedRiceContents prc[8]; unsigned prc_alloc[8];
+	/* frames whose header is valid but differs from STREAMINFO (channels, sample size, a block longer than the maximum):
+	 * the reference decodes them with the frame's own parameters (:2002-2145); here a second device decoder built for
+	 * those parameters takes the frame, and the event carries its samples */
+	flacamd_decoder *alt_eng; unsigned alt_ch, alt_bps, alt_bs; size_t alt_bytes;
+	struct alt_frame { int32_t *pcm; flacamd_subframe_info sub[8]; unsigned ch, bps; } **f_alt;
+	size_t planar_cap;
 	int search_warned;               /* LOST_SYNC already reported for the sync search in progress (frame_sync_'s `first`) */
 	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
 	int32_t *planar; uint8_t *md5_scratch;
@@ -90,6 +96,8 @@ static void dec_free(FLAC__StreamDecoder *d)
 	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
 	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
 	free(d->sub); d->sub = 0; free(d->f_cand); d->f_cand = 0; free(d->frame_cand); d->frame_cand = 0;
+	if(d->f_alt) { unsigned r; for(r = 0; r < d->ev_cap; r++) if(d->f_alt[r]) { free(d->f_alt[r]->pcm); free(d->f_alt[r]); } free(d->f_alt); d->f_alt = 0; }
+	if(d->alt_eng) { flacamd_decoder_destroy(d->alt_eng); d->alt_eng = 0; }
 	{ unsigned c; for(c = 0; c < 8; c++) { free(d->prc[c].parameters); free(d->prc[c].raw_bits); d->prc[c].parameters = d->prc[c].raw_bits = 0; d->prc_alloc[c] = 0; } }
 }
 
@@ -338,7 +346,9 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 		d->ev_cap = 4u * d->eng_frames + 64u;
 		d->sub = (flacamd_subframe_info*)malloc(sizeof(flacamd_subframe_info) * (size_t)d->eng_frames * si->channels);
 		d->f_cand = (uint32_t*)malloc(4u * d->ev_cap); d->frame_cand = (uint32_t*)malloc(4u * d->eng_frames);
-		if(!d->sub || !d->f_cand || !d->frame_cand) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		d->f_alt = (struct alt_frame**)calloc(d->ev_cap, sizeof(struct alt_frame*));
+		d->planar_cap = (size_t)si->max_blocksize * si->channels;
+		if(!d->sub || !d->f_cand || !d->frame_cand || !d->f_alt) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->pcm = (int32_t*)malloc(sizeof(int32_t) * d->pcm_cap * si->channels);
 		d->f_off = (uint64_t*)malloc(8u * d->ev_cap); d->f_num = (uint64_t*)malloc(8u * d->ev_cap); d->f_end = (uint64_t*)malloc(8u * d->ev_cap); d->f_sn = (uint64_t*)malloc(8u * d->ev_cap);
 		d->f_bs = (uint32_t*)malloc(4u * d->ev_cap); d->f_asg = (uint32_t*)malloc(4u * d->ev_cap); d->f_kind = (uint8_t*)malloc(d->ev_cap);
@@ -423,7 +433,8 @@ static void push_event_c(FLAC__StreamDecoder *d, unsigned kind, unsigned status_
 /* read_frame_header_ (:2147-2454) on the bytes after a sync code at b[s]: 0 = a header the reference accepts,
  * 1 = BAD_HEADER, 3 = UNPARSEABLE_STREAM (the error status values), -1 = the buffer ends inside the header.
  * *resume = where the search for the next sync code starts after a rejection. */
-static int probe_header(const FLAC__StreamDecoder *d, const uint8_t *b, size_t n, size_t s, size_t *resume)
+struct host_header { unsigned blocksize, channels, assignment, bps, hdr_len; uint64_t number; };
+static int probe_header(const FLAC__StreamDecoder *d, const uint8_t *b, size_t n, size_t s, size_t *resume, struct host_header *hh)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
 	uint8_t raw[16]; unsigned len = 2, i, extra, unparseable = 0, bs_hint = 0, sr_hint = 0, x; size_t p = s + 2; uint8_t crc = 0;
@@ -457,7 +468,71 @@ static int probe_header(const FLAC__StreamDecoder *d, const uint8_t *b, size_t n
 	*resume = p + 1;
 	if(crc != b[p]) return 1;      /* :2416-2420 */
 	if(unparseable) return 3;      /* :2447-2451 */
+	if(hh) { /* the fields as read_frame_header_ resolves them (:2203-2360, :2378-2414) */
+		const unsigned bs_code = raw[2] >> 4, ch_code = raw[3] >> 4, bps_code = (raw[3] >> 1) & 7u; unsigned at = 5 + extra; uint64_t v;
+		const uint8_t lead = raw[4];
+		v = extra == 0 ? lead : extra == 6 ? 0 : (uint64_t)(lead & (0x7fu >> (extra + 1)));
+		for(i = 0; i < extra; i++) v = (v << 6) | (raw[5 + i] & 0x3fu);
+		hh->number = v;
+		if(bs_code == 1) hh->blocksize = 192; else if(bs_code <= 5) hh->blocksize = 576u << (bs_code - 2); else if(bs_code == 6) hh->blocksize = raw[at] + 1u;
+		else if(bs_code == 7) hh->blocksize = (((unsigned)raw[at] << 8) | raw[at + 1]) + 1u; else hh->blocksize = 256u << (bs_code - 8);
+		if(ch_code < 8) { hh->channels = ch_code + 1; hh->assignment = 0; } else { hh->channels = 2; hh->assignment = ch_code - 7; }
+		switch(bps_code) { case 1: hh->bps = 8; break; case 2: hh->bps = 12; break; case 4: hh->bps = 16; break; case 5: hh->bps = 20; break; case 6: hh->bps = 24; break; default: hh->bps = si->bits_per_sample; break; }
+		hh->hdr_len = len + 1;
+	}
 	return 0;
+}
+
+/* One frame whose parameters differ from the stream's, through a device decoder made for them.  Returns 1 when an event
+ * (or several) was queued and *end is where the walk goes on, 0 when the frame runs past the bytes at hand, -1 on failure. */
+static int decode_alt_frame(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, size_t s, const struct host_header *hh, int variable, size_t *end)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	const size_t bound = 16 + (size_t)hh->channels * (((size_t)hh->blocksize * (hh->bps + 2) + 7) / 8 + 64) + 2;
+	size_t window = n - s < bound ? n - s : bound;
+	uint64_t info[4] = { 0, 0, 0, 0 }, c_pos[8], c_end[8], c_num[8], c_off[8]; uint32_t c_info[8], c_bs[8], nc = 0;
+	struct alt_frame *af; int rc; uint64_t sn;
+	if(hh->bps < 4 || hh->bps > 24) return -1;
+	if(!d->alt_eng || d->alt_ch != hh->channels || d->alt_bps != hh->bps || d->alt_bs < hh->blocksize) {
+		if(d->alt_eng) { flacamd_decoder_destroy(d->alt_eng); d->alt_eng = 0; }
+		d->alt_bytes = 16 + (size_t)hh->channels * (((size_t)hh->blocksize * (hh->bps + 2) + 7) / 8 + 64) + 2 + 64;
+		if(flacamd_decoder_create(&d->alt_eng, d->device, hh->channels, hh->bps, hh->blocksize, 8, d->alt_bytes) != FLACAMD_OK) return -1;
+		(void)flacamd_decoder_set_tolerant(d->alt_eng, 1);
+		if(flacamd_decoder_set_subframe_info(d->alt_eng, 1) != FLACAMD_OK) return -1;
+		d->alt_ch = hh->channels; d->alt_bps = hh->bps; d->alt_bs = hh->blocksize;
+	}
+	af = (struct alt_frame*)calloc(1, sizeof *af);
+	if(!af || !(af->pcm = (int32_t*)calloc((size_t)hh->blocksize * hh->channels, sizeof(int32_t)))) { free(af); return -1; }
+	af->ch = hh->channels; af->bps = hh->bps;
+	/* the window may show more sync codes than the few candidates this decoder holds: shrink it to the frame's bound first */
+	for(;;) {
+		rc = flacamd_decode_host(d->alt_eng, b + s, window, af->pcm, FLACAMD_PCM_S32, hh->blocksize, info);
+		if(rc == FLACAMD_E_CAPACITY && window > 64) { window = window * 3 / 4; continue; }
+		break;
+	}
+	if(rc == FLACAMD_OK) rc = flacamd_decoder_candidate_table(d->alt_eng, 8, &nc, c_pos, c_end, c_info, c_bs, c_num, c_off);
+	if(rc != FLACAMD_OK || nc == 0 || c_pos[0] != 0) { free(af->pcm); free(af); return -1; }
+	{
+		flacamd_subframe_info recs[8 * 8];
+		if(flacamd_decoder_subframe_info(d->alt_eng, 8, recs, 0, 0) == FLACAMD_OK) memcpy(af->sub, recs, sizeof(flacamd_subframe_info) * hh->channels);
+	}
+	sn = variable ? hh->number : hh->number * (uint64_t)si->min_blocksize;
+	*end = s + (size_t)c_end[0];
+	if(!(c_info[0] & 1u)) {
+		const uint32_t ex = (c_info[0] >> 8) & 15u;
+		free(af->pcm); free(af);
+		if(ex == 6u) return 0;
+		push_event(d, EV_ERROR, ex == 4u ? FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM : FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, *end);
+		return 1;
+	}
+	if(!((c_info[0] & 2u) && c_off[0] == 0)) { /* CRC mismatch: an error report and a frame of zeros (:2111-2119) */
+		memset(af->pcm, 0, sizeof(int32_t) * (size_t)hh->blocksize * hh->channels);
+		push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH, 0, 0, 0, *end);
+	}
+	push_event(d, EV_FRAME, (c_info[0] >> 4) & 15u, hh->blocksize, 0, sn, *end);
+	d->f_num[d->q_n - 1] = s;
+	d->f_alt[d->q_n - 1] = af;
+	return 1;
 }
 
 /* returns bytes consumed; sets d->state only through queued events */
@@ -468,7 +543,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 	FLAC__uint64 sd = d->samples_decoded;
 	size_t pos = 0; unsigned ci = 0;
 	for(;;) {
-		size_t s, resume = 0; int hr;
+		size_t s, resume = 0; int hr; struct host_header hh;
 		if(d->q_n + 4u > d->ev_cap) return pos;
 		if(total > 0 && sd >= total) { push_event(d, EV_END, 0, 0, 0, 0, pos); return pos; } /* :1952-1959 */
 		/* frame_sync_ :1967-1997 */
@@ -489,7 +564,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 		if(s > pos && !d->search_warned) push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, s);
 		d->search_warned = 0;
 		/* read_frame_header_ */
-		hr = probe_header(d, b, n, s, &resume);
+		hr = probe_header(d, b, n, s, &resume, &hh);
 		if(hr < 0) {
 			if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
 			if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
@@ -500,9 +575,17 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 		if(ci >= ncand || d->c_pos[ci] != s) {
 			/* a header the reference would go on to decode with parameters that differ from STREAMINFO's
 			 * (or a blocksize above its maximum): the device decoder is built for the stream's parameters */
-			push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, 0, 0, 0, s);
-			push_event(d, EV_ABORT, 0, 0, 0, 0, s);
-			return s;
+			size_t aend = s; int ar;
+			const int variable = (b[s + 1] & 1) || si->min_blocksize != si->max_blocksize;
+			ar = decode_alt_frame(d, b, n, s, &hh, variable, &aend);
+			if(ar == 0) { /* the frame runs past the bytes at hand */
+				if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
+				if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+				return s;
+			}
+			if(ar < 0) { push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, 0, 0, 0, s); push_event(d, EV_ABORT, 0, 0, 0, 0, s); return s; }
+			if(d->f_kind[d->q_n - 1] == EV_FRAME) sd = d->f_sn[d->q_n - 1] + hh.blocksize;
+			pos = aend; continue;
 		}
 		{
 			const uint32_t info = d->c_info[ci], ex = (info >> 8) & 15u; const uint64_t end = d->c_end[ci];
@@ -532,12 +615,20 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 	}
 }
 
+/* forget the queued events (their frames with parameters of their own included) */
+static void drop_events(FLAC__StreamDecoder *d)
+{
+	unsigned k;
+	for(k = 0; d->f_alt && k < d->q_n; k++) if(d->f_alt[k]) { free(d->f_alt[k]->pcm); free(d->f_alt[k]); d->f_alt[k] = 0; }
+	d->q_n = d->q_i = 0;
+}
+
 /* decode the next batch of frames on the device; leaves q_n > q_i, or a terminal state */
 static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
 	size_t window; uint64_t info[4] = {0, 0, 0, 0}; int rc; unsigned r;
-	d->q_n = d->q_i = 0;
+	drop_events(d);
 	if(si->total_samples > 0 && d->samples_decoded >= si->total_samples) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; } /* :1966-1970 */
 	if(!fill(d, d->batch_bytes)) return 0;
 	if(avail(d) == 0) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
@@ -573,7 +664,7 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 }
 
 /* the sample rate out of the frame's own header bytes, and the subframe records of its candidate */
-static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const uint8_t *fb, size_t flen, uint32_t cand)
+static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const uint8_t *fb, size_t flen, const flacamd_subframe_info *recs)
 {
 	static const unsigned rates[12] = { 0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000 };
 	const unsigned ch = frame->header.channels; unsigned c;
@@ -587,7 +678,7 @@ static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const
 		/* header.crc and footer.crc stay 0: the reference's decoder checks both CRCs but never stores them in the frame it hands out */
 	}
 	for(c = 0; c < ch && c < 8; c++) {
-		const flacamd_subframe_info *rec = &d->sub[(size_t)cand * ch + c];
+		const flacamd_subframe_info *rec = &recs[c];
 		FLAC__Subframe *sf = &frame->subframes[c];
 		const unsigned type = rec->head & 3u, order = (rec->head >> 2) & 63u, po = (rec->head >> 19) & 15u; unsigned i;
 		FLAC__EntropyCodingMethod *ecm = 0;
@@ -628,7 +719,7 @@ static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const
 static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
-	FLAC__Frame frame; const FLAC__int32 *bufs[8]; unsigned r, c, n, ch = si->channels, skip = 0, kind; const int32_t *src; size_t i;
+	FLAC__Frame frame; const FLAC__int32 *bufs[8]; unsigned r, c, n, ch = si->channels, bps = si->bits_per_sample, skip = 0, kind; const int32_t *src; size_t i; struct alt_frame *alt;
 	for(;;) {
 		if(d->q_i == d->q_n) {
 			if(!decode_batch(d)) return 0;
@@ -644,41 +735,48 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 		break;
 	}
 	n = d->f_bs[r];
-	src = kind == EV_FRAME ? d->pcm + d->f_off[r] * ch : 0;
+	alt = d->f_alt[r]; d->f_alt[r] = 0;
+	if(alt) { ch = alt->ch; bps = alt->bps; src = alt->pcm; }   /* a frame with parameters of its own (decode_alt_frame) */
+	else src = kind == EV_FRAME ? d->pcm + d->f_off[r] * ch : 0;
+	if((size_t)n * ch > d->planar_cap) { /* longer than the stream's maximum says: the reference reallocates its output too (:2012) */
+		int32_t *np = (int32_t*)realloc(d->planar, sizeof(int32_t) * (size_t)n * ch);
+		if(!np) { if(alt) { free(alt->pcm); free(alt); } d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		d->planar = np; d->planar_cap = (size_t)n * ch;
+	}
 	if(d->f_sn[r] != ~(uint64_t)0) d->samples_decoded = d->f_sn[r]; /* :2135: the header's number, not a running count */
 	memset(&frame, 0, sizeof frame);
 	frame.header.blocksize = n; frame.header.sample_rate = si->sample_rate; frame.header.channels = ch;
-	frame.header.channel_assignment = (FLAC__ChannelAssignment)d->f_asg[r]; frame.header.bits_per_sample = si->bits_per_sample;
+	frame.header.channel_assignment = (FLAC__ChannelAssignment)d->f_asg[r]; frame.header.bits_per_sample = bps;
 	frame.header.number_type = FLAC__FRAME_NUMBER_TYPE_SAMPLE_NUMBER;
 	frame.header.number.sample_number = d->samples_decoded; /* frame number x fixed blocksize for the streams this decoder takes (:2422-2445) */
 	{ /* what read_frame_header_ / read_subframe_* leave in the frame (:2147-2454, :2456-2719) */
 		const uint8_t *fb = d->in + d->batch_in_off + d->f_num[r]; const size_t flen = (size_t)(d->f_end[r] - d->f_num[r]);
-		fill_frame_details(d, &frame, fb, flen, d->f_cand[r]);
+		fill_frame_details(d, &frame, fb, flen, alt ? alt->sub : &d->sub[(size_t)d->f_cand[r] * ch]);
 	}
 	d->last = frame.header;
 	if(d->do_md5 && deliver) {
-		if(src) md5_feed_pcm(&d->md5, src, (size_t)n * ch, si->bits_per_sample, d->md5_scratch, 65536);
+		if(src) md5_feed_pcm(&d->md5, src, (size_t)n * ch, bps, d->md5_scratch, 65536);
 		else { /* a zeroed frame goes through the checksum like any other (:2964) */
-			size_t left = (size_t)n * ch;
-			memset(d->planar, 0, sizeof(int32_t) * (size_t)si->max_blocksize * ch);
-			while(left) { const size_t k = left < (size_t)si->max_blocksize * ch ? left : (size_t)si->max_blocksize * ch; md5_feed_pcm(&d->md5, d->planar, k, si->bits_per_sample, d->md5_scratch, 65536); left -= k; }
+			memset(d->planar, 0, sizeof(int32_t) * (size_t)n * ch);
+			md5_feed_pcm(&d->md5, d->planar, (size_t)n * ch, bps, d->md5_scratch, 65536);
 		}
 	}
 	if(d->is_seeking) { /* :2920-2956: drop frames before the target, trim the one that holds it */
 		const FLAC__uint64 first = d->samples_decoded;
-		if(d->target_sample >= first + n) { d->samples_decoded += n; return 1; }
+		if(d->target_sample >= first + n) { d->samples_decoded += n; if(alt) { free(alt->pcm); free(alt); } return 1; }
 		skip = (unsigned)(d->target_sample - first);
 		d->is_seeking = 0;
 		frame.header.blocksize = n - skip; frame.header.number.sample_number = first + skip;
 	}
 	d->samples_decoded += n;
-	if(!deliver) return 1;
+	if(!deliver) { if(alt) { free(alt->pcm); free(alt); } return 1; }
 	for(c = 0; c < ch; c++) {
-		int32_t *dst = d->planar + (size_t)c * si->max_blocksize;
+		int32_t *dst = d->planar + (size_t)c * n;
 		if(src) for(i = skip; i < n; i++) dst[i - skip] = src[i * ch + c];
 		else memset(dst, 0, sizeof(int32_t) * n);
 		bufs[c] = dst;
 	}
+	if(alt) { free(alt->pcm); free(alt); }
 	for(c = 0; c < ch; c++) if(frame.subframes[c].type == FLAC__SUBFRAME_TYPE_VERBATIM) frame.subframes[c].data.verbatim.data = bufs[c];
 	if(d->write_cb(d, &frame, bufs, d->client_data) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
 	return 1;
@@ -740,7 +838,8 @@ FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *d) /* :952-973 */
 {
 	if(!d || d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
 	d->samples_decoded = 0; d->do_md5 = 0;
-	d->in_base += d->in_len; d->in_len = d->in_pos = 0; d->eof = 0; d->q_n = d->q_i = 0;
+	drop_events(d);
+	d->in_base += d->in_len; d->in_len = d->in_pos = 0; d->eof = 0;
 	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
 	return 1;
 }
@@ -774,7 +873,8 @@ FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *d, FLAC__uint
 	/* every frame decodes independently and a batch costs milliseconds, so the target is found by
 	 * decoding forward from the first frame rather than by the reference's bisection (:2992-3225) */
 	if(d->seek_cb(d, d->first_frame_offset, d->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
-	d->in_base = d->first_frame_offset; d->in_len = d->in_pos = 0; d->eof = 0; d->q_n = d->q_i = 0; d->samples_decoded = 0;
+	drop_events(d);
+	d->in_base = d->first_frame_offset; d->in_len = d->in_pos = 0; d->eof = 0; d->samples_decoded = 0;
 	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
 	d->target_sample = sample;
 	while(d->is_seeking) {

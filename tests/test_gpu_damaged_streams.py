@@ -199,3 +199,64 @@ def test_random_damage(gpu_engine, seed):
         p = int(rng.integers(audio, len(bad)))
         bad[p] ^= int(rng.integers(1, 256))
     _same(bad, batch=[None, 1, 2, 7][seed % 4], read_chunk=[None, 1000, None][seed % 3])
+
+
+# ---- frames whose header is valid but disagrees with STREAMINFO -------------------------------------------------
+
+def _run_frames(lib, data, batch=None):
+    d = stream.StreamDecoder(bytes(data), seekable=False, lib=lib)
+    if lib is None and batch:
+        assert d.set_batch_frames(batch)
+    assert d.set_md5_checking(True)
+    assert d.init() == 0
+    ok = d.process_until_end_of_stream()
+    out = dict(ok=ok, state=d.get_state(), events=list(d.events), frames=[(h, p.copy()) for h, p in d.frames],
+               last=(d.get_channels(), d.get_bits_per_sample(), d.get_sample_rate(), d.get_blocksize()))
+    out["finish"] = d.finish()
+    d.close()
+    return out
+
+
+def _foreign_frames(kind):
+    if kind == "mono16":
+        pcm = synth.music_like(0.3, seed=41)[:9000, :1]
+        _, rp = ob.make_params(1, 16, 44100, level=5, blocksize=1152)
+    elif kind == "st24":
+        pcm = synth.multichannel_24(0.1, rate=44100, channels=2, seed=42)[:4000]
+        _, rp = ob.make_params(2, 24, 44100, level=8, blocksize=1152)
+    elif kind == "st8":
+        pcm = (synth.music_like(0.2, seed=43)[:5000] >> 8).astype(np.int32)
+        _, rp = ob.make_params(2, 8, 44100, level=3, blocksize=576)
+    elif kind == "long":    # same format, blocks longer than the stream's maximum
+        pcm = synth.music_like(0.5, seed=44)[:3 * 4096]
+        _, rp = ob.make_params(2, 16, 44100, level=8, blocksize=4096)
+    elif kind == "rate":    # same format, another sample rate in the header
+        pcm = synth.music_like(0.2, seed=45)[:3 * 1152]
+        _, rp = ob.make_params(2, 16, 32000, level=5, blocksize=1152)
+    else:                   # 6 channels
+        pcm = synth.multichannel_24(0.05, rate=44100, channels=6, seed=46)[:2000]
+        _, rp = ob.make_params(6, 24, 44100, level=5, blocksize=1152)
+    return ob.ref_encode(rp, pcm)["frames"]
+
+
+@pytest.mark.parametrize("kind,where,count,batch", [("mono16", 5, 2, None), ("st24", 0, 1, 7), ("st8", 11, 3, None), ("long", 7, 2, 3), ("rate", 3, 2, None),
+                                                    ("ch6", 9, 1, None), ("mono16", 40, 1, 2)])
+def test_frames_with_parameters_of_their_own(gpu_engine, kind, where, count, batch):
+    """The reference decodes a frame by its own header (stream_decoder.c:2002-2145): frames of another stream spliced in
+    come out with their own channels / sample size / blocksize / sample rate, and the stream goes on after them."""
+    data, audio, sizes = _stream("st16")
+    offs = _offsets(audio, sizes)
+    cut = offs[min(where, len(sizes) - 1)]
+    foreign = b"".join(_foreign_frames(kind)[:count])
+    spliced = data[:cut] + foreign + data[cut:]
+    ref = _run_frames(_ref_decoder_lib(), spliced)
+    got = _run_frames(None, spliced, batch=batch)
+    assert got["events"] == ref["events"]
+    assert got["ok"] == ref["ok"] and got["state"] == ref["state"] and got["finish"] == ref["finish"] and got["last"] == ref["last"]
+    assert len(got["frames"]) == len(ref["frames"])
+    shapes = set()
+    for (hg, pg), (hr, pr) in zip(got["frames"], ref["frames"]):
+        assert hg == hr
+        assert pg.shape == pr.shape and np.array_equal(pg, pr)
+        shapes.add((hg["channels"], hg["bits_per_sample"], hg["sample_rate"]))
+    assert len(shapes) == 2 or kind == "long"
