@@ -46,7 +46,7 @@ struct FLAC__StreamDecoder {
 	/* input window: in[in_pos, in_len) is unread, in[0] sits at absolute stream offset in_base */
 	uint8_t *in; size_t in_cap, in_len, in_pos; FLAC__uint64 in_base; int eof, warned_sync;
 	/* device decoder and the batch it produced */
-	flacamd_decoder *eng; size_t batch_bytes; unsigned eng_frames;
+	flacamd_decoder *eng; size_t batch_bytes, frame_bound; unsigned eng_frames;
 	int32_t *pcm; size_t pcm_cap;
 	/* the batch as a queue of events in stream order: frames, and on damaged input also zeroed frames, error
 	 * reports and the end of the stream (f_kind); f_sn is the sample number from the frame header where the
@@ -69,6 +69,10 @@ struct FLAC__StreamDecoder {
 	md5_state md5;
 	FLAC__FrameHeader last;
 	FLAC__bool is_seeking; FLAC__uint64 target_sample;
+	/* the stream's first SEEKTABLE, kept whatever the metadata filter says (the reference keeps it for seeking too, :1623-1650) */
+	FLAC__StreamMetadata_SeekPoint *seek_points; unsigned num_seek_points;
+	int resync_base;   /* after flush(): the client may have repositioned its input, ask tell_cb where the next read starts */
+	int want_grow;     /* a frame longer than the input window: make the window larger and try again */
 };
 
 static void dec_defaults(FLAC__StreamDecoder *d) /* set_defaults_, :1247-1268 */
@@ -95,6 +99,7 @@ static void dec_free(FLAC__StreamDecoder *d)
 	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
 	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
 	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
+	free(d->seek_points); d->seek_points = 0; d->num_seek_points = 0;
 	free(d->sub); d->sub = 0; free(d->f_cand); d->f_cand = 0; free(d->frame_cand); d->frame_cand = 0;
 	if(d->f_alt) { unsigned r; for(r = 0; r < d->ev_cap; r++) if(d->f_alt[r]) { free(d->f_alt[r]->pcm); free(d->f_alt[r]); } free(d->f_alt); d->f_alt = 0; }
 	if(d->alt_eng) { flacamd_decoder_destroy(d->alt_eng); d->alt_eng = 0; }
@@ -258,9 +263,19 @@ FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder
 }
 
 /* ---- input: make at least `need` unread bytes available (fewer at end of stream) */
-static FLAC__bool fill(FLAC__StreamDecoder *d, size_t need)
+static FLAC__bool fill_range(FLAC__StreamDecoder *d, size_t least, size_t want);
+static FLAC__bool fill(FLAC__StreamDecoder *d, size_t need) { return fill_range(d, need, need); }
+
+/* at least `least` unread bytes (fewer at end of stream), reading towards `want`: a source that delivers little per
+ * call (a pipe, a live stream) is not waited on for a whole window, a file fills it in one call */
+static FLAC__bool fill_range(FLAC__StreamDecoder *d, size_t least, size_t need)
 {
-	if(d->in_len - d->in_pos >= need) return 1;
+	if(d->in_len - d->in_pos >= least) return 1;
+	if(d->resync_base && d->in_len == d->in_pos) {
+		FLAC__uint64 at = 0;
+		if(d->tell_cb && d->tell_cb(d, &at, d->client_data) == FLAC__STREAM_DECODER_TELL_STATUS_OK) { d->in_base = at; d->in_len = d->in_pos = 0; }
+		d->resync_base = 0;
+	}
 	if(d->in_pos > 0) { /* compact */
 		memmove(d->in, d->in + d->in_pos, d->in_len - d->in_pos);
 		d->in_base += d->in_pos; d->in_len -= d->in_pos; d->in_pos = 0;
@@ -270,7 +285,7 @@ static FLAC__bool fill(FLAC__StreamDecoder *d, size_t need)
 		if(!nb) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->in = nb; d->in_cap = need;
 	}
-	while(d->in_len < need && !d->eof) {
+	while(d->in_len < least && !d->eof) {
 		size_t n = d->in_cap - d->in_len;
 		const FLAC__StreamDecoderReadStatus st = d->read_cb(d, d->in + d->in_len, &n, d->client_data);
 		if(st == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
@@ -318,6 +333,7 @@ static FLAC__bool find_metadata(FLAC__StreamDecoder *d)
 	}
 }
 
+static FLAC__bool make_engine(FLAC__StreamDecoder *d);
 static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
@@ -330,19 +346,20 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 	d->decode_pos = d->first_frame_offset;
 	if(!d->eng) {
 		max_frame = 16 + (size_t)si->channels * (((size_t)si->max_blocksize * (si->bits_per_sample + 2) + 7) / 8 + 64) + 2;
-		if(si->max_framesize + 16u > max_frame) max_frame = (size_t)si->max_framesize + 16u;   /* the stream says its frames are longer than the usual bound */
+		d->frame_bound = max_frame;
+		/* STREAMINFO's max_framesize is advisory (the reference never sizes anything by it) and comes from the file: it may
+		 * make the window larger, within limits - a frame that still does not fit makes the window grow when it is met */
+		if(si->max_framesize + 16u > max_frame && si->max_framesize <= ((size_t)1 << 20)) max_frame = (size_t)si->max_framesize + 16u;
 		d->batch_bytes = max_frame * d->batch_frames;
+		if(d->batch_bytes > ((size_t)256 << 20)) d->batch_bytes = (size_t)256 << 20;
+		if(d->batch_bytes < 2 * max_frame) d->batch_bytes = 2 * max_frame;
 		if(d->batch_bytes < ((size_t)1 << 16)) d->batch_bytes = (size_t)1 << 16;
 		/* the device decoder's capacity counts every candidate that passes the header checks, and a
 		 * window of batch_bytes may hold more (shorter) frames than batch_frames: leave room, and let
 		 * decode_batch shrink its window when even that is exceeded */
 		d->eng_frames = 2u * d->batch_frames + 256u;
 		d->pcm_cap = (size_t)d->eng_frames * si->max_blocksize;
-		if(flacamd_decoder_create(&d->eng, d->device, si->channels, si->bits_per_sample, si->max_blocksize, d->eng_frames, d->batch_bytes) != FLACAMD_OK) {
-			d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0;
-		}
-		(void)flacamd_decoder_set_tolerant(d->eng, 1);
-		if(flacamd_decoder_set_subframe_info(d->eng, 1) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		if(!make_engine(d)) return 0;
 		d->ev_cap = 4u * d->eng_frames + 64u;
 		d->sub = (flacamd_subframe_info*)malloc(sizeof(flacamd_subframe_info) * (size_t)d->eng_frames * si->channels);
 		d->f_cand = (uint32_t*)malloc(4u * d->ev_cap); d->frame_cand = (uint32_t*)malloc(4u * d->eng_frames);
@@ -371,7 +388,11 @@ static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
 	p = d->in + d->in_pos;
 	is_last = p[0] >> 7; type = p[0] & 0x7f; length = ((FLAC__uint64)p[1] << 16) | ((FLAC__uint64)p[2] << 8) | p[3];
 	d->in_pos += 4;
-	if(type == 0 && length >= 34) { /* stream_decoder.c:1792-1869, layout format.c:68-86 */
+	if(type == 0 && length < 34) { /* not a STREAMINFO this decoder can use: passed over, never handed out as one */
+		d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client_data);
+		if(!skip_bytes(d, length)) return 0;
+	}
+	else if(type == 0) { /* stream_decoder.c:1792-1869, layout format.c:68-86 */
 		FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
 		FLAC__uint64 x;
 		if(!fill(d, 34)) return 0;
@@ -399,14 +420,36 @@ static FLAC__bool read_metadata(FLAC__StreamDecoder *d)
 			if(!fill(d, 4)) return 0;
 			if(avail(d) >= 4) for(i = 0; i < d->app_ids_count; i++) if(0 == memcmp(d->in + d->in_pos, d->app_ids + 4 * i, 4)) { deliver = !d->respond[type]; break; }
 		}
+		if(type == FLAC__METADATA_TYPE_SEEKTABLE && !d->seek_points && length >= FLAC__STREAM_METADATA_SEEKPOINT_LENGTH) { /* :1623-1650: kept for seek_absolute */
+			if(!fill(d, (size_t)length)) return 0;
+			if(avail(d) >= length) {
+				const unsigned np = (unsigned)(length / FLAC__STREAM_METADATA_SEEKPOINT_LENGTH); unsigned i, k;
+				d->seek_points = (FLAC__StreamMetadata_SeekPoint*)malloc(sizeof(FLAC__StreamMetadata_SeekPoint) * np);
+				if(d->seek_points) {
+					for(i = 0; i < np; i++) {
+						const uint8_t *q = d->in + d->in_pos + (size_t)i * FLAC__STREAM_METADATA_SEEKPOINT_LENGTH; FLAC__uint64 a = 0, o = 0;
+						for(k = 0; k < 8; k++) { a = (a << 8) | q[k]; o = (o << 8) | q[8 + k]; }
+						d->seek_points[i].sample_number = a; d->seek_points[i].stream_offset = o; d->seek_points[i].frame_samples = ((unsigned)q[16] << 8) | q[17];
+					}
+					d->num_seek_points = np;
+				}
+			}
+		}
 		if(deliver) {
 			FLAC__StreamMetadata block;
 			if(!fill(d, (size_t)length)) return 0;
 			if(avail(d) < length) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
-			if(flacamd_metadata_block_parse(type, (int)is_last, d->in + d->in_pos, (size_t)length, &block) != 0) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
-			d->in_pos += (size_t)length;
-			d->metadata_cb(d, &block, d->client_data);
-			flacamd_metadata_block_free(&block);
+			if(flacamd_metadata_block_parse(type, (int)is_last, d->in + d->in_pos, (size_t)length, &block) != 0) {
+				/* contents that contradict the block's length (or no memory for them): the block is passed over with a
+				 * report and the audio still decodes */
+				d->error_cb(d, FLAC__STREAM_DECODER_ERROR_STATUS_BAD_HEADER, d->client_data);
+				d->in_pos += (size_t)length;
+			}
+			else {
+				d->in_pos += (size_t)length;
+				d->metadata_cb(d, &block, d->client_data);
+				flacamd_metadata_block_free(&block);
+			}
 		}
 		else if(!skip_bytes(d, length)) return 0;
 	}
@@ -567,7 +610,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 		hr = probe_header(d, b, n, s, &resume, &hh);
 		if(hr < 0) {
 			if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
-			if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+			if(s == 0 && n >= d->batch_bytes) { d->want_grow = 1; return 0; }
 			return s;
 		}
 		if(hr > 0) { push_event(d, EV_ERROR, (unsigned)hr, 0, 0, 0, resume); pos = resume; continue; }
@@ -580,7 +623,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 			ar = decode_alt_frame(d, b, n, s, &hh, variable, &aend);
 			if(ar == 0) { /* the frame runs past the bytes at hand */
 				if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
-				if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+				if(s == 0 && n >= d->batch_bytes) { d->want_grow = 1; return 0; }
 				return s;
 			}
 			if(ar < 0) { push_event(d, EV_ERROR, FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM, 0, 0, 0, s); push_event(d, EV_ABORT, 0, 0, 0, 0, s); return s; }
@@ -592,7 +635,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 			if(!(info & 1u)) {
 				if(ex == 6u) { /* the frame runs past the buffer */
 					if(at_eof) { push_event(d, EV_END_FAIL, 0, 0, 0, 0, n); return n; }
-					if(s == 0 && n >= d->batch_bytes) { push_event(d, EV_ABORT, 0, 0, 0, 0, 0); return 0; }
+					if(s == 0 && n >= d->batch_bytes) { d->want_grow = 1; return 0; }
 					return s;
 				}
 				/* the subframe-level rejections (:2481, :2494-2508, :2580, :2628, :2732-2745, :2785); fields the
@@ -623,44 +666,71 @@ static void drop_events(FLAC__StreamDecoder *d)
 	d->q_n = d->q_i = 0;
 }
 
+/* a device decoder for the stream's parameters taking up to d->batch_bytes per call */
+static FLAC__bool make_engine(FLAC__StreamDecoder *d)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	if(d->eng) { flacamd_decoder_destroy(d->eng); d->eng = 0; }
+	if(flacamd_decoder_create(&d->eng, d->device, si->channels, si->bits_per_sample, si->max_blocksize, d->eng_frames, d->batch_bytes) != FLACAMD_OK
+		|| flacamd_decoder_set_tolerant(d->eng, 1) != FLACAMD_OK || flacamd_decoder_set_subframe_info(d->eng, 1) != FLACAMD_OK) {
+		d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0;
+	}
+	return 1;
+}
+
 /* decode the next batch of frames on the device; leaves q_n > q_i, or a terminal state */
 static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 {
 	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
-	size_t window; uint64_t info[4] = {0, 0, 0, 0}; int rc; unsigned r;
+	size_t window, least; uint64_t info[4] = {0, 0, 0, 0}; int rc; unsigned r;
 	drop_events(d);
 	if(si->total_samples > 0 && d->samples_decoded >= si->total_samples) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; } /* :1966-1970 */
-	if(!fill(d, d->batch_bytes)) return 0;
-	if(avail(d) == 0) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
-	window = avail(d) < d->batch_bytes ? avail(d) : d->batch_bytes;
+	/* enough input for one frame of the usual size at least; whatever one read call delivers beyond that is taken along */
+	least = d->frame_bound < d->batch_bytes ? d->frame_bound : d->batch_bytes;
 	for(;;) {
-		rc = flacamd_decode_host(d->eng, d->in + d->in_pos, window, d->pcm, FLACAMD_PCM_S32, d->pcm_cap, info);
-		if(rc == FLACAMD_E_CAPACITY && window > 1024u) { window /= 2; continue; } /* more frames in the window than a batch holds */
-		break;
-	}
-	if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
-	d->batch_base = d->in_base + d->in_pos; d->batch_in_off = d->in_pos;
-	if(flacamd_decoder_subframe_info(d->eng, d->eng_frames, d->sub, d->frame_cand, d->eng_frames) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
-	if(flacamd_decoder_damage(d->eng) == 0) {
-		const uint8_t *b = d->in + d->in_pos;
-		if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, d->c_pos, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
-		d->q_n = (unsigned)info[0];
-		for(r = 0; r < d->q_n; r++) { /* the sample number as read_frame_header_ derives it (:2346-2376, :2422-2445) */
-			const int variable = (b[d->c_pos[r] + 1] & 1) || si->min_blocksize != si->max_blocksize;
-			d->f_kind[r] = EV_FRAME; d->f_sn[r] = variable ? d->f_num[r] : d->f_num[r] * (uint64_t)si->min_blocksize;
-			d->f_cand[r] = d->frame_cand[r]; d->f_num[r] = d->c_pos[r];   /* from here on: where the frame starts in the batch */
+		if(!fill_range(d, least, d->batch_bytes)) return 0;
+		if(avail(d) == 0) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
+		window = avail(d) < d->batch_bytes ? avail(d) : d->batch_bytes;
+		for(;;) {
+			rc = flacamd_decode_host(d->eng, d->in + d->in_pos, window, d->pcm, FLACAMD_PCM_S32, d->pcm_cap, info);
+			if(rc == FLACAMD_E_CAPACITY && window > 1024u) { window /= 2; continue; } /* more frames in the window than a batch holds */
+			break;
 		}
-		d->search_warned = 0;
-		d->in_pos += (size_t)info[3];
+		if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
+		d->batch_base = d->in_base + d->in_pos; d->batch_in_off = d->in_pos;
+		if(flacamd_decoder_subframe_info(d->eng, d->eng_frames, d->sub, d->frame_cand, d->eng_frames) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		if(flacamd_decoder_damage(d->eng) == 0) {
+			const uint8_t *b = d->in + d->in_pos;
+			if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, d->c_pos, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+			d->q_n = (unsigned)info[0];
+			for(r = 0; r < d->q_n; r++) { /* the sample number as read_frame_header_ derives it (:2346-2376, :2422-2445) */
+				const int variable = (b[d->c_pos[r] + 1] & 1) || si->min_blocksize != si->max_blocksize;
+				d->f_kind[r] = EV_FRAME; d->f_sn[r] = variable ? d->f_num[r] : d->f_num[r] * (uint64_t)si->min_blocksize;
+				d->f_cand[r] = d->frame_cand[r]; d->f_num[r] = d->c_pos[r];   /* from here on: where the frame starts in the batch */
+			}
+			d->search_warned = 0;
+			d->in_pos += (size_t)info[3];
+			return 1;
+		}
+		{
+			uint32_t ncand = 0; size_t used;
+			if(flacamd_decoder_candidate_table(d->eng, d->eng_frames, &ncand, d->c_pos, d->c_end, d->c_info, d->c_bs, d->c_num, d->c_off) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+			d->want_grow = 0;
+			used = walk_damaged(d, d->in + d->in_pos, window, d->eof && window == avail(d), ncand);
+			d->in_pos += used;
+			if(d->q_n > 0 || used > 0) return 1;
+			/* nothing could be decided: the first frame of the window is not all there yet */
+			if(d->want_grow) { /* it is longer than the window: a larger window (frames of up to 16 MiB exist, format.c:72) */
+				if(d->batch_bytes >= ((size_t)1 << 30)) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+				d->batch_bytes *= 2;
+				if(!make_engine(d)) return 0;
+				least = d->batch_bytes;
+				continue;
+			}
+			if(!d->eof && avail(d) < d->batch_bytes) { least = avail(d) + 1; continue; }   /* more input */
+			d->state = FLAC__STREAM_DECODER_ABORTED; return 0;
+		}
 	}
-	else {
-		uint32_t ncand = 0; size_t used;
-		if(flacamd_decoder_candidate_table(d->eng, d->eng_frames, &ncand, d->c_pos, d->c_end, d->c_info, d->c_bs, d->c_num, d->c_off) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
-		used = walk_damaged(d, d->in + d->in_pos, window, d->eof && window == avail(d), ncand);
-		if(d->q_n == 0 && used == 0) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; } /* cannot happen: no progress */
-		d->in_pos += used;
-	}
-	return 1;
 }
 
 /* the sample rate out of the frame's own header bytes, and the subframe records of its candidate */
@@ -839,7 +909,8 @@ FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *d) /* :952-973 */
 	if(!d || d->state == FLAC__STREAM_DECODER_UNINITIALIZED) return 0;
 	d->samples_decoded = 0; d->do_md5 = 0;
 	drop_events(d);
-	d->in_base += d->in_len; d->in_len = d->in_pos = 0; d->eof = 0;
+	d->in_base += d->in_len; d->in_len = d->in_pos = 0; d->eof = 0; d->decode_pos = 0;
+	d->resync_base = 1;   /* the client may reposition its input now: the next read asks tell_cb where it starts */
 	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
 	return 1;
 }
@@ -856,9 +927,38 @@ FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *d) /* :975-1040 */
 	return 1;
 }
 
+/* The first CRC-valid frame at or after absolute byte offset `at`: its offset and the number of its first sample.
+ * Reads a window of a few frames there and lets the device decode every plausible position in it (sync code +
+ * CRC-8 + CRC-16 are what make a frame start certain, as in frame_sync_ / read_frame_, :1947-2145). */
+static int probe_at(FLAC__StreamDecoder *d, FLAC__uint64 at, FLAC__uint64 *frame_pos, FLAC__uint64 *frame_sample)
+{
+	const FLAC__StreamMetadata_StreamInfo *si = &d->streaminfo.data.stream_info;
+	size_t want = 4 * d->frame_bound + 65536, got = 0; uint64_t info[4]; uint32_t nc = 0, i; uint8_t *buf; int found = 0;
+	if(want > d->batch_bytes) want = d->batch_bytes;
+	if(d->seek_cb(d, at, d->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) return -1;
+	if(!(buf = (uint8_t*)malloc(want))) return -1;
+	while(got < want) {
+		size_t n = want - got;
+		const FLAC__StreamDecoderReadStatus st = d->read_cb(d, buf + got, &n, d->client_data);
+		if(st == FLAC__STREAM_DECODER_READ_STATUS_ABORT) { free(buf); return -1; }
+		got += n;
+		if(st == FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM || n == 0) break;
+	}
+	if(got >= 16 && flacamd_decode_host(d->eng, buf, got, d->pcm, FLACAMD_PCM_S32, d->pcm_cap, info) == FLACAMD_OK
+		&& flacamd_decoder_candidate_table(d->eng, d->eng_frames, &nc, d->c_pos, d->c_end, d->c_info, d->c_bs, d->c_num, d->c_off) == FLACAMD_OK) {
+		for(i = 0; i < nc && !found; i++) if((d->c_info[i] & 3u) == 3u) {
+			const int variable = (buf[d->c_pos[i] + 1] & 1) || si->min_blocksize != si->max_blocksize;
+			*frame_pos = at + d->c_pos[i]; *frame_sample = variable ? d->c_num[i] : d->c_num[i] * (FLAC__uint64)si->min_blocksize;
+			found = 1;
+		}
+	}
+	free(buf);
+	return found;
+}
+
 FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *d, FLAC__uint64 sample) /* :1124-1180 */
 {
-	FLAC__uint64 total;
+	FLAC__uint64 total, lo_byte, lo_sample = 0, hi_byte = 0, hi_sample, length = 0, near; unsigned i, tries;
 	if(!d) return 0;
 	if(d->state != FLAC__STREAM_DECODER_SEARCH_FOR_METADATA && d->state != FLAC__STREAM_DECODER_READ_METADATA && d->state != FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC
 		&& d->state != FLAC__STREAM_DECODER_READ_FRAME && d->state != FLAC__STREAM_DECODER_END_OF_STREAM) return 0;
@@ -869,12 +969,36 @@ FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *d, FLAC__uint
 		if(!FLAC__stream_decoder_process_until_end_of_metadata(d)) { d->is_seeking = 0; return 0; }
 	}
 	total = FLAC__stream_decoder_get_total_samples(d);
-	if(!d->has_streaminfo || (total > 0 && sample >= total)) { d->is_seeking = 0; return 0; }
-	/* every frame decodes independently and a batch costs milliseconds, so the target is found by
-	 * decoding forward from the first frame rather than by the reference's bisection (:2992-3225) */
-	if(d->seek_cb(d, d->first_frame_offset, d->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+	if(!d->has_streaminfo || !d->eng || (total > 0 && sample >= total)) { d->is_seeking = 0; return 0; }
 	drop_events(d);
-	d->in_base = d->first_frame_offset; d->in_len = d->in_pos = 0; d->eof = 0; d->samples_decoded = 0;
+	/* Where to start decoding: a frame that begins at or before the target and as close to it as is cheap to find.
+	 * seek_to_absolute_sample_ (:2979-3192) narrows a byte range with the seek table and then by interpolation, reading one
+	 * frame per step; here a step is one small device decode that says which frame starts where, and the forward decode
+	 * that follows drops what lies before the target - so the range only has to shrink to about a batch. */
+	lo_byte = d->first_frame_offset; hi_sample = total;
+	if(d->length_cb && d->length_cb(d, &length, d->client_data) == FLAC__STREAM_DECODER_LENGTH_STATUS_OK) hi_byte = length;
+	for(i = 0; i < d->num_seek_points; i++) { /* :3021-3094: the closest points on either side */
+		const FLAC__StreamMetadata_SeekPoint *pt = &d->seek_points[i];
+		if(pt->sample_number == FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER_VALUE || pt->frame_samples == 0 || (total > 0 && pt->sample_number >= total)) continue;
+		if(hi_byte && d->first_frame_offset + pt->stream_offset >= hi_byte) continue;
+		if(pt->sample_number <= sample && pt->sample_number >= lo_sample) { lo_sample = pt->sample_number; lo_byte = d->first_frame_offset + pt->stream_offset; }
+		else if(pt->sample_number > sample && pt->sample_number < hi_sample) { hi_sample = pt->sample_number; if(hi_byte) hi_byte = d->first_frame_offset + pt->stream_offset; }
+	}
+	near = (FLAC__uint64)d->batch_frames * d->streaminfo.data.stream_info.max_blocksize / 4;
+	for(tries = 0; tries < 24 && hi_byte > lo_byte && total > 0 && hi_sample > lo_sample && sample - lo_sample > near; tries++) {
+		/* interpolate (:3124-3135), aiming a little short of the target so that the frame found starts before it */
+		FLAC__uint64 aim = sample - lo_sample > near / 2 ? sample - near / 2 : lo_sample, guess, fpos = 0, fsample = 0; int pr;
+		guess = lo_byte + (FLAC__uint64)((double)(aim - lo_sample) / (double)(hi_sample - lo_sample) * (double)(hi_byte - lo_byte));
+		if(guess >= hi_byte) guess = hi_byte - 1;
+		if(guess <= lo_byte) break;
+		pr = probe_at(d, guess, &fpos, &fsample);
+		if(pr < 0) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+		if(pr == 0 || fsample > sample || fpos >= hi_byte) { hi_byte = guess; if(pr > 0 && fsample > sample && fsample < hi_sample) hi_sample = fsample; continue; }
+		if(fpos <= lo_byte) break;
+		lo_byte = fpos; lo_sample = fsample;
+	}
+	if(d->seek_cb(d, lo_byte, d->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) { d->is_seeking = 0; d->state = FLAC__STREAM_DECODER_SEEK_ERROR; return 0; }
+	d->in_base = lo_byte; d->in_len = d->in_pos = 0; d->eof = 0; d->samples_decoded = lo_sample; d->resync_base = 0; d->search_warned = 1;
 	d->state = FLAC__STREAM_DECODER_SEARCH_FOR_FRAME_SYNC;
 	d->target_sample = sample;
 	while(d->is_seeking) {

@@ -1,6 +1,8 @@
 """GPU tests of the libFLAC-style stream decoder object (include/flac_amd_stream.h): whole
 streams as the reference writes them go in through the read callback; frames, headers,
 STREAMINFO, MD5 verdict and seek behaviour come out as with the reference decoder."""
+import os
+
 import numpy as np
 import pytest
 
@@ -165,4 +167,116 @@ def test_file_decoder_round_trip_with_reference_encoder(gpu_engine, tmp_path):
     assert d.process_until_end_of_stream()
     assert np.array_equal(d.pcm(), pcm)
     assert d.finish()
+    d.close()
+
+
+# ---- seeking by seek table and interpolation, bounded input, robustness against what the file claims -------------
+
+class _CountingBytes:
+    """the input of a decoder that counts the bytes asked of it"""
+
+    def __init__(self, data):
+        self.data, self.count = data, 0
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, sl):
+        out = self.data[sl]
+        self.count += len(out)
+        return out
+
+
+def _long_file(tmp_path, seconds, extra):
+    import struct
+    import subprocess
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "flac")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/flac not built")
+    pcm = synth.music_like(seconds, seed=321)
+    data = pcm.astype("<i2").tobytes()
+    wav = str(tmp_path / "long.wav")
+    with open(wav, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 176400, 4, 16) + b"data" + struct.pack("<I", len(data)))
+        f.write(data)
+    out = str(tmp_path / "long.flac")
+    subprocess.run([ref, "--silent", "-f", "-5"] + extra + ["-o", out, wav], check=True, timeout=300)
+    return pcm, open(out, "rb").read()
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-seektable"], ["-S", "1s"]])
+def test_seek_in_a_long_stream_reads_a_fraction_of_it(gpu_engine, tmp_path, extra):
+    """seek_to_absolute_sample_ (stream_decoder.c:2979-3192) narrows the search with the seek table and by interpolation; the
+    frames delivered after a seek are the ones the reference delivers, and the input read for it stays far below the stream's size."""
+    pcm, data = _long_file(tmp_path, 240.0, extra)
+    n = len(pcm)
+    rng = np.random.default_rng(5)
+    src = _CountingBytes(data)
+    d = stream.StreamDecoder(src, seekable=True)
+    assert d.set_batch_frames(64) and d.init() == 0
+    assert d.process_until_end_of_metadata()
+    for target in [n - 1, 0, n // 2, 4095, 4096] + [int(v) for v in rng.integers(0, n, 12)]:
+        d.frames = []
+        before = src.count
+        assert d.seek_absolute(target), target
+        assert len(d.frames) == 1 and d.frames[0][0]["sample_number"] == target
+        got = d.frames[0][1].T
+        assert np.array_equal(got, pcm[target:target + got.shape[0]])
+        assert d.process_single() or True
+        assert src.count - before < len(data) // 4, (target, src.count - before, len(data))
+        if len(d.frames) > 1:
+            h, p = d.frames[1]
+            assert h["sample_number"] == target + got.shape[0] and np.array_equal(p.T, pcm[h["sample_number"]:h["sample_number"] + p.shape[1]])
+    d.close()
+
+
+def test_a_streaminfo_that_claims_huge_frames_still_decodes(gpu_engine):
+    """max_framesize comes from the file and is advisory (the reference never sizes anything by it)."""
+    g = load_golden("st16-level5")
+    data = bytearray(_stream_of(g))
+    data[4 + 4 + 7:4 + 4 + 10] = b"\xff\xff\xff"        # STREAMINFO max_framesize = 0xFFFFFF
+    d = stream.StreamDecoder(bytes(data), seekable=False)
+    assert d.set_md5_checking(1) and d.init() == 0
+    assert d.process_until_end_of_stream() and d.get_state() == stream.DEC_END_OF_STREAM
+    assert np.array_equal(d.pcm(), g["pcm"]) and d.finish()
+    d.close()
+
+
+def test_input_that_trickles_in_is_decoded_as_it_arrives(gpu_engine):
+    """A source that hands over a few hundred bytes per read (a pipe, a live stream): frames come out as soon as they are
+    complete, not when a whole window of megabytes has arrived."""
+    if not ob.have_ref():
+        pytest.skip("oracle/_ref not built")
+    pcm = synth.music_like(3.0, seed=77)
+    _, rp = ob.make_params(2, 16, 44100, level=8)
+    r = ob.ref_encode(rp, pcm)
+    data = ob.stream_head(4096, 4096, r["min_framesize"], r["max_framesize"], 44100, 2, 16, len(pcm), r["md5"], is_last=False) + r["stream"][42:]
+    g = dict(pcm=pcm)
+
+    class Slow(stream.StreamDecoder):
+        def write_callback(self, header, pcm):
+            self.seen.append(self.pos)           # how far the input had been read when this frame came out
+            return super().write_callback(header, pcm)
+
+    d = Slow(data, seekable=False, read_chunk=700)
+    d.seen = []
+    assert d.set_md5_checking(1) and d.init() == 0
+    assert d.process_until_end_of_stream()
+    assert np.array_equal(d.pcm(), g["pcm"]) and d.finish()
+    assert len(data) > 300000 and d.seen[0] < 40000, "the first frame waited for a whole window"
+    assert all(b - a < 60000 for a, b in zip(d.seen, d.seen[1:]))
+    d.close()
+
+
+def test_a_metadata_block_with_inconsistent_contents_is_passed_over(gpu_engine):
+    g = load_golden("mono16-8")
+    data = _stream_of(g)
+    # a VORBIS_COMMENT whose vendor length runs past the block, between STREAMINFO and the frames
+    bad = bytes([4, 0, 0, 12]) + (500).to_bytes(4, "little") + bytes(8)
+    spliced = data[:42] + bad + data[42:]       # STREAMINFO, the bad block, then the stream's own (last) VORBIS_COMMENT and the frames
+    d = stream.StreamDecoder(spliced, seekable=False)
+    assert d.set_metadata_respond_all() and d.set_md5_checking(1) and d.init() == 0
+    assert d.process_until_end_of_stream() and d.get_state() == stream.DEC_END_OF_STREAM
+    assert np.array_equal(d.pcm(), g["pcm"]) and d.finish()
+    assert d.errors == [1] and len(d.metadata) == 1      # BAD_HEADER reported, nothing handed out for the bad block; the good one arrives
     d.close()
