@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
 
 
 # kernel that runs each timed stage for this workload (16-bit stereo, blocksize 4096)
-KERNEL_OF_STAGE = {"prep": "fa_prep_stereo16_kernel", "autoc": "fa_autoc_ms16_kernel<13>", "model": "fa_model_kernel<12>",
+KERNEL_OF_STAGE = {"prep_beside_autoc": "fa_prep_stereo16_kernel", "autoc_join_wait": "fa_autoc_ms16_kernel<13>", "model": "fa_model_kernel<12>",
                    "search": "fa_search_fast_kernel<unsigned int, 1, 1>", "pack": "fa_pack_fast_kernel<2>", "gather": "fa_gather_kernel"}
 
 
@@ -494,7 +494,7 @@ def main():
                        "frames_per_gpu": nframes, "wide_samples_per_gpu": nsamples, "parallelism": "frame ranges x%d" % world,
                        "compressed_bytes_per_gpu": total_bytes, "ratio": round(total_bytes / (nsamples * 4), 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limited_by": "integer VALU issue (see note)", "kernel": KERNEL_OF_STAGE.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(KERNEL_OF_STAGE.get(dom, dom), args.minutes),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer VALU-bound kernel: ~(order+5) lane-ops per sample per LPC candidate, so the HBM fraction is small by nature; stage_ms has the per-stage times"},

@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 // ------------------------------------------------------------------ host side
 
 static thread_local char fd_last_error[256] = "";
-extern "C" const char *flacamd_last_error(void);
+extern "C" void fa_set_last_error(const char *msg);   // engine.hip: what flacamd_last_error() returns
 
 struct flacamd_decoder {
 	int device;
@@ -767,7 +767,7 @@ struct flacamd_decoder {
 	void *d_subinfo;
 };
 
-#define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
+#define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); fa_set_last_error(fd_last_error); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
 
 static size_t fd_align(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -799,7 +799,7 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 		o_fo = take((size_t)max_frames * 4), o_so = take((size_t)max_frames * 8), o_res = take(256), o_tab = take(4096);
 	d->arena_bytes = off;
 	hipError_t he = hipMalloc(&d->arena, off);
-	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
+	if(he != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "hipMalloc(decoder arena %zu): %s", off, hipGetErrorString(he)); fa_set_last_error(fd_last_error); free(d); return FLACAMD_E_OUT_OF_MEMORY; }
 	uint8_t *b = (uint8_t*)d->arena;
 	FdWork &w = d->work;
 	w.wg_count = (uint32_t*)(b + o_cnt); w.wg_off = (uint32_t*)(b + o_woff); w.scan_mask = (uint16_t*)(b + o_mask); w.ncand = (uint32_t*)(b + o_nc); w.cand_pos = (uint64_t*)(b + o_pos); w.cand_end = (uint64_t*)(b + o_end);

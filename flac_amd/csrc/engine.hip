@@ -40,6 +40,8 @@ static int hip_fail(hipError_t e, const char *what)
 #define HIP_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return hip_fail(e_, #call); } while(0)
 
 extern "C" const char *flacamd_last_error(void) { return g_last_error; }
+// for the other translation units of the library (the decoder): one message buffer per thread, one getter
+extern "C" void fa_set_last_error(const char *msg) { snprintf(g_last_error, sizeof g_last_error, "%s", msg ? msg : ""); }
 
 extern "C" const char *flacamd_strerror(int code)
 {

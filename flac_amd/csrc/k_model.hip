@@ -33,6 +33,12 @@ __device__ __forceinline__ double expected_bits_scaled(double err, double scale)
 	return err < 0.0 ? 1e32 : 0.0;
 }
 
+// fixed.c:256-268: bits per residual sample expected of a fixed predictor whose |residual| sum is e over len samples
+__device__ __forceinline__ float fixed_expected_bits(unsigned long long e, double len)
+{
+	return (float)((e > 0) ? log(FA_LN2 * (double)e / len) / FA_LN2 : 0.0);
+}
+
 // Quantise coefficients c[0..order) at `precision` bits and emit one lpc candidate
 // (lpc.c:156-263; precision clamp and datapath choice stream_encoder.c:3587-3603).
 template<int MAXORD>
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 #pragma unroll
 		for(int k = 0; k < 5; k++) {
 			e[k] = w.fixed_err[(size_t)k * c.G + g];
-			fb[k] = (float)((e[k] > 0) ? log(FA_LN2 * (double)e[k] / len) / FA_LN2 : 0.0);
+			fb[k] = fixed_expected_bits(e[k], len);
 		}
 		uint32_t guess;
 		{
@@ -239,4 +245,38 @@ extern "C" void fa_launch_model(const FaCfg *c, const FaWork *w, hipStream_t st)
 	const dim3 grid((c->G + 63u) / 64u), block(64);
 	if(c->max_lpc_order <= 12) hipLaunchKernelGGL(fa_model_kernel<12>, grid, block, 0, st, *c, *w);
 	else hipLaunchKernelGGL(fa_model_kernel<32>, grid, block, 0, st, *c, *w);
+}
+
+// ---- the two logarithms above, on inputs of the caller's choosing.  Every float decision downstream of them (the
+// Rice parameter suggested to a candidate, the "not worth trying" skip, the order guess) goes through these two
+// expressions, and log() is the one operation in them that IEEE 754 does not pin: the parity tests sweep the
+// neighbourhood of every decision boundary through this entry point and compare with the host's libm.
+__global__ void __launch_bounds__(256) fa_model_logs_kernel(uint32_t n, const unsigned long long *__restrict__ e, const double *__restrict__ len,
+	const double *__restrict__ err, const double *__restrict__ scale, float *__restrict__ fb, double *__restrict__ eb)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if(i >= n) return;
+	fb[i] = fixed_expected_bits(e[i], len[i]);
+	eb[i] = expected_bits_scaled(err[i], scale[i]);
+}
+
+extern "C" int flacamd_debug_model_logs(int device, uint32_t n, const uint64_t *h_e, const double *h_len, const double *h_err, const double *h_scale, float *h_fb, double *h_eb)
+{
+	if(!n || !h_e || !h_len || !h_err || !h_scale || !h_fb || !h_eb) return FLACAMD_E_INVALID_ARGUMENT;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FLACAMD_E_NO_DEVICE;
+	if(hipSetDevice(device) != hipSuccess) return FLACAMD_E_DEVICE;
+	uint8_t *d = 0;
+	const size_t N = n;
+	if(hipMalloc((void**)&d, N * (8 + 8 + 8 + 8 + 4 + 8)) != hipSuccess) return FLACAMD_E_OUT_OF_MEMORY;
+	unsigned long long *de = (unsigned long long*)d; double *dl = (double*)(d + N * 8), *dr = (double*)(d + N * 16), *ds = (double*)(d + N * 24), *deb = (double*)(d + N * 32); float *dfb = (float*)(d + N * 40);
+	int rc = FLACAMD_OK;
+	if(hipMemcpy(de, h_e, N * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dl, h_len, N * 8, hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(dr, h_err, N * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ds, h_scale, N * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FLACAMD_E_DEVICE;
+	if(rc == FLACAMD_OK) {
+		hipLaunchKernelGGL(fa_model_logs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, 0, n, de, dl, dr, ds, dfb, deb);
+		if(hipMemcpy(h_fb, dfb, N * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(h_eb, deb, N * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FLACAMD_E_DEVICE;
+	}
+	(void)hipFree(d);
+	return rc;
 }

@@ -171,7 +171,9 @@ class Encoder:
     def last_timing(self):
         ms = (C.c_float * 6)()
         _check(self._lib.flacamd_encoder_last_timing(self._h, C.byref(ms)), "flacamd_encoder_last_timing")
-        return dict(zip(("prep", "autoc", "model", "search", "pack", "gather"), [float(v) for v in ms]))
+        # prep and the autocorrelation run side by side on two streams: the first interval ends when prep does, the
+        # second is what was left of the autocorrelation to wait for at the join
+        return dict(zip(("prep_beside_autoc", "autoc_join_wait", "model", "search", "pack", "gather"), [float(v) for v in ms]))
 
     def encode_host(self, pcm, final=True, first_frame=0, prev_assignment=0):
         """pcm: numpy (samples, channels) int32 or int16. Returns (list of frame bytes, last assignment)."""

@@ -52,7 +52,7 @@ def stitch(sizes_per_rank, bytes_per_rank):
                 min_framesize=int(sizes.min()) if len(sizes) else 0, max_framesize=int(sizes.max()) if len(sizes) else 0)
 
 
-def encode_sharded(encode_range, nsamples, blocksize, align=1, group=None, device="cpu"):
+def encode_sharded(encode_range, nsamples, blocksize, align=None, group=None, device="cpu"):
     """Encode one stream of `nsamples` wide samples on all ranks of `group`.
 
     encode_range(first_frame, first_sample, end_sample, final) -> list of frame bytes for that
@@ -62,6 +62,9 @@ def encode_sharded(encode_range, nsamples, blocksize, align=1, group=None, devic
     import torch
     import torch.distributed as dist
 
+    if align is None:
+        raise ValueError("align: pass loose_mid_side_period(sample_rate, blocksize) for loose mid/side streams (presets 1 and 4), 1 otherwise - "
+                         "a range that starts inside a decision period would code other bytes than the reference")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     nframes = -(-nsamples // blocksize)

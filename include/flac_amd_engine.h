@@ -196,8 +196,14 @@ void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues);
  * nsignals = frames x (4 for mid/side stereo, else channels). Returns bytes written or <0. */
 long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h_dst, size_t cap);
 
+/* White-box view for parity tests: the two logarithm expressions of the model stage (fixed.c:256-268: bits expected of a
+ * fixed predictor from its |residual| sum e over len samples; lpc.c:1336-1351: bits expected of an LPC order from its
+ * prediction error and scale), evaluated on the device for n inputs of the caller's choosing. */
+int flacamd_debug_model_logs(int device, uint32_t n, const uint64_t *h_e, const double *h_len, const double *h_err, const double *h_scale, float *h_fb, double *h_eb);
+
 /* Kernel time of the stages of the last batch in milliseconds, measured with HIP events on
- * the stream the kernels ran on: ms[0..5] = prep, autocorrelation, model, search, pack, gather.
+ * the stream the kernels ran on: ms[0..5] = prep (the autocorrelation runs beside it on a second stream), what was left
+ * of the autocorrelation to wait for when prep had ended, model, search, pack, gather.
  * Valid only when the batch was submitted with timing enabled. */
 void flacamd_encoder_set_timing(flacamd_encoder *e, int enabled);
 int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6]);
