@@ -18,8 +18,12 @@ def _engine_params(engine, ch, bps, rate, kw):
 
 
 def _encode(engine, ch, bps, rate, kw, pcm, **enc_kw):
+    import ctypes as C
     p = _engine_params(engine, ch, bps, rate, kw)
-    enc = engine.Encoder(p, max_frames=max(1, (len(pcm) + 15) // 16 if p.blocksize and p.blocksize < 64 else len(pcm) // 16 + 2))
+    # exactly the frames the input makes at the resolved blocksize: a capacity bug shows, and the arenas stay small
+    q = engine.Params.from_buffer_copy(p)
+    bs = int(q.blocksize) if engine.lib().flacamd_params_resolve(C.byref(q)) == 0 else 16
+    enc = engine.Encoder(p, max_frames=max(1, -(-len(pcm) // max(bs, 1))))
     try:
         return enc, enc.encode_host(pcm, **enc_kw)
     except Exception:

@@ -30,73 +30,87 @@ def signal(rng, kind, n, ch, bps):
         cols[1] = np.clip(cols[0] + rng.integers(-3, 4, n), -peak - 1, peak).astype(np.int32)   # nearly identical channels: side signal near zero
     return np.stack(cols, axis=1)
 
+def case(seed):
+    """The seeded case: (channels, bits per sample, rate, encoder settings, pcm, effective blocksize)."""
+    rng = np.random.default_rng(zlib.crc32(b"fuzz%d" % seed))
+    ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
+    bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24]))
+    level = int(rng.integers(0, 9))
+    bs = int(rng.choice([0, 0, 16, 192, 576, 1000, 1152, 2304, 4096, 4096, 4608, 5000, 8192, 16384, 20000]))
+    kw = dict(level=level)
+    if bs:
+        kw["blocksize"] = bs
+    if rng.integers(4) == 0:
+        kw["do_qlp_coeff_prec_search"] = 1
+    if rng.integers(4) == 0:
+        kw["max_lpc_order"] = int(rng.integers(0, 33))
+    if rng.integers(4) == 0:
+        kw["max_residual_partition_order"] = int(rng.integers(0, 9))
+    if rng.integers(6) == 0:
+        kw["qlp_coeff_precision"] = int(rng.integers(5, 16))
+    if rng.integers(8) == 0:
+        kw["do_exhaustive_model_search"] = 1
+    if rng.integers(8) == 0:
+        kw["apodization"] = [("tukey", 0.25), ("hann", 0), ("blackman", 0)][:int(rng.integers(1, 4))]
+    if rng.integers(10) == 0:
+        kw["disable_fixed"] = 1
+    if rng.integers(10) == 0:
+        kw["disable_verbatim"] = 1
+    if rng.integers(10) == 0:
+        kw["disable_constant"] = 1
+    if rng.integers(8) == 0:
+        kw["min_residual_partition_order"] = int(rng.integers(0, 5))
+    eff = bs or (4096 if kw.get("max_lpc_order", 1 if level >= 3 else 0) else 1152)
+    n = int(rng.integers(1, 4)) * eff + int(rng.integers(0, eff))
+    n = min(n, 70000)
+    pcm = signal(rng, int(rng.integers(6)), n, ch, bps)
+    rate = int(rng.choice([8000, 44100, 48000, 96000]))
+    return ch, bps, rate, kw, pcm, eff
+
+
+def run_seed(seed):
+    """None when the reference refuses the configuration, else (identical?, description): frames from the device engine
+    against the oracle's, the oracle's frames back through the device decoder, and the 16-bit input layout."""
+    ch, bps, rate, kw, pcm, eff = case(seed)
+    n = len(pcm)
+    what = "seed %d: ch %d bps %d rate %d %r n %d" % (seed, ch, bps, rate, kw, n)
+    fp, _ = ob.make_params(ch, bps, rate, **kw)
+    try:
+        want = ob.oracle_encode(fp, pcm)["frames"]
+    except RuntimeError:
+        return None   # a configuration the reference refuses (e.g. blocksize <= max_lpc_order)
+    enc, (frames, _) = tp._encode(engine, ch, bps, rate, kw, pcm)
+    enc.close()
+    if frames != want:
+        return False, what + " (frames differ)"
+    blob = b"".join(want)
+    dec = engine.Decoder(ch, bps, max(eff, 16), max_frames=len(want) + 64, max_bytes=len(blob) + 64)
+    back, info = dec.decode_host(blob, n + eff)
+    dec.close()
+    if info["frames"] != len(want) or not np.array_equal(back, pcm):
+        return False, what + " (decoder differs)"
+    if bps <= 16:
+        enc, (frames16, _) = tp._encode(engine, ch, bps, rate, kw, pcm.astype(np.int16))
+        enc.close()
+        if frames16 != want:
+            return False, what + " (16-bit input layout differs)"
+    return True, what
+
+
 def main():
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
     for seed in range(first, first + ncase):
-        rng = np.random.default_rng(zlib.crc32(b"fuzz%d" % seed))
-        ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
-        bps = int(rng.choice([8, 12, 16, 16, 16, 20, 24]))
-        level = int(rng.integers(0, 9))
-        bs = int(rng.choice([0, 0, 16, 192, 576, 1000, 1152, 2304, 4096, 4096, 4608, 5000, 8192, 16384, 20000]))
-        kw = dict(level=level)
-        if bs:
-            kw["blocksize"] = bs
-        if rng.integers(4) == 0:
-            kw["do_qlp_coeff_prec_search"] = 1
-        if rng.integers(4) == 0:
-            kw["max_lpc_order"] = int(rng.integers(0, 33))
-        if rng.integers(4) == 0:
-            kw["max_residual_partition_order"] = int(rng.integers(0, 9))
-        if rng.integers(6) == 0:
-            kw["qlp_coeff_precision"] = int(rng.integers(5, 16))
-        if rng.integers(8) == 0:
-            kw["do_exhaustive_model_search"] = 1
-        if rng.integers(8) == 0:
-            kw["apodization"] = [("tukey", 0.25), ("hann", 0), ("blackman", 0)][:int(rng.integers(1, 4))]
-        if rng.integers(10) == 0:
-            kw["disable_fixed"] = 1
-        if rng.integers(10) == 0:
-            kw["disable_verbatim"] = 1
-        if rng.integers(10) == 0:
-            kw["disable_constant"] = 1
-        if rng.integers(8) == 0:
-            kw["min_residual_partition_order"] = int(rng.integers(0, 5))
-        eff = bs or (4096 if kw.get("max_lpc_order", 1 if level >= 3 else 0) else 1152)
-        n = int(rng.integers(1, 4)) * eff + int(rng.integers(0, eff))
-        n = min(n, 70000)
-        pcm = signal(rng, int(rng.integers(6)), n, ch, bps)
-        rate = int(rng.choice([8000, 44100, 48000, 96000]))
         try:
-            fp, _ = ob.make_params(ch, bps, rate, **kw)
-            try:
-                want = ob.oracle_encode(fp, pcm)["frames"]
-            except RuntimeError:
-                continue   # a configuration the reference refuses (e.g. blocksize <= max_lpc_order)
-            enc, (frames, _) = tp._encode(engine, ch, bps, rate, kw, pcm)
-            enc.close()
-            same = frames == want
-            if same:   # and back through the device decoder
-                blob = b"".join(want)
-                dec = engine.Decoder(ch, bps, max(eff, 16), max_frames=len(want) + 64, max_bytes=len(blob) + 64)
-                back, info = dec.decode_host(blob, n + eff)
-                dec.close()
-                if info["frames"] != len(want) or not np.array_equal(back, pcm):
-                    same = False
-                    print("seed", seed, "decoder differs")
-            if same and bps <= 16:
-                enc, (frames16, _) = tp._encode(engine, ch, bps, rate, kw, pcm.astype(np.int16))
-                enc.close()
-                same = frames16 == want
+            r = run_seed(seed)
         except Exception as ex:
-            same = False
-            print("seed", seed, "exception", repr(ex)[:200])
+            r = (False, "seed %d exception %s" % (seed, repr(ex)[:200]))
         if seed % 500 == 499:
             print("... seed", seed, "differing so far", bad, flush=True)
-        if not same:
+        if r is not None and not r[0]:
             bad += 1
-            print("seed", seed, "differs: ch", ch, "bps", bps, "rate", rate, kw, "n", n, flush=True)
+            print(r[1], flush=True)
     print("cases", ncase, "differing", bad)
 
 if __name__ == "__main__":
