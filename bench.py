@@ -34,10 +34,10 @@ KERNEL_OF_STAGE = {"prep_beside_autoc": "fa_prep_stereo16_kernel", "autoc_join_w
 
 def pmc_traffic(kernel, minutes):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r1_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    command (profiles/r2_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate
     runs, FETCH_SIZE doubled as measured for gfx950), or None when no pass covers it."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")) as f:
             summ = json.load(f)
         if summ.get("minutes") != minutes:
             return None
@@ -496,6 +496,7 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "limited_by": "integer VALU issue (see note)", "kernel": KERNEL_OF_STAGE.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(KERNEL_OF_STAGE.get(dom, dom), args.minutes),
+                         "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/r2_pmc_summary.json), not measured in this run",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer VALU-bound kernel: ~(order+5) lane-ops per sample per LPC candidate, so the HBM fraction is small by nature; stage_ms has the per-stage times"},
         }

@@ -5,7 +5,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/dpmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT" -o p -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 > "$OUT.log" 2>&1 || { echo "pmc pass failed"; tail -5 "$OUT.log"; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT" -o p -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-configs --no-api --steps 1 --warmup 1 > "$OUT.log" 2>&1 || { echo "pmc pass failed"; tail -5 "$OUT.log"; exit 1; }
 python3 - <<EOF
 import csv, glob, collections
 f = glob.glob("$OUT/**/p_counter_collection.csv", recursive=True)[0]
