@@ -264,10 +264,12 @@ FLAC__bool flacamd_stream_encoder_set_fill_threads(FLAC__StreamEncoder *encoder,
  * replayed frame by frame in stream order: the write callback sees the same FLAC__FrameHeader
  * fields and the same planar FLAC__int32 buffers as with the reference.
  *
- * Differences, none silent: Ogg transport is not provided; a stream must begin with STREAMINFO; a
- * batch that contains corrupt frames is reported through the error callback and decoding stops
- * (state ABORTED) instead of resynchronising inside the batch; FLAC__Frame carries the header and
- * the footer CRC but no per-subframe records.
+ * Differences, none silent: Ogg transport is not provided; a stream must begin with STREAMINFO;
+ * callbacks arrive a batch of frames at a time.  Damaged input is handled as the reference handles
+ * it (the same error reports, zeroed frames and resynchronisation points: the serial walk of
+ * frame_sync_ / read_frame_ is replayed on the host over what the device decoded), frames whose
+ * header differs from STREAMINFO are decoded with their own parameters, and FLAC__Frame carries
+ * subframes[] (see FLAC__Frame below for the two pointers that stay NULL / point elsewhere).
  * ====================================================================================== */
 
 typedef enum {
