@@ -315,6 +315,18 @@ struct BitReader {
 	}
 };
 
+// a pick between two values that both exist already (comes out as one conditional move)
+static __device__ __forceinline__ uint32_t fd_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+static __device__ __forceinline__ int fd_sel(bool c, int a, int b) { return c ? a : b; }
+
+// d = a.lo16 * b.lo16 + a.hi16 * b.hi16 + c on signed halves, wrapping
+static __device__ __forceinline__ int32_t fd_dot2(uint32_t a, uint32_t b, int32_t c)
+{
+	int32_t d;
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+	return d;
+}
+
 #define FD_RING 32u
 #define FD_REGORD 12
 
@@ -337,6 +349,7 @@ struct FdPipe {
 	uint32_t more[2];
 };
 
+template<bool SUBINFO>
 __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
 	__shared__ FdPipe pipe;
@@ -376,7 +389,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 			// ---- head of the subframe (per lane, no barrier inside)
 			uint32_t bps = h.bps, wasted = 0, order = 0, type = 0, nres = 0, po = 0, plen = 4, esc = 15;
 			// what the reference keeps in FLAC__Subframe for the client (stream_decoder.c:2456-2719), when asked for
-			flacamd_subframe_info *const sub = (c.subinfo && live) ? w.subinfo + ((size_t)ci * c.channels + ch) : (flacamd_subframe_info*)0;
+			flacamd_subframe_info *const sub = (SUBINFO && live) ? w.subinfo + ((size_t)ci * c.channels + ch) : (flacamd_subframe_info*)0;
 			if((h.assignment == 1 && ch == 1) || (h.assignment == 2 && ch == 0) || (h.assignment == 3 && ch == 1)) bps++; // stream_decoder.c:2027-2055
 			if(ok) do {
 				uint32_t head = br.read(8);
@@ -419,65 +432,149 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				if(br.err) ok = false;
 			} while(0);
 			hand_over(false);
-			// ---- one value per step for every lane that still has some (residuals, or the samples of a verbatim subframe);
-			// partition headers are read where a partition runs out
-			// Every step refills the window once (at least 33 bits) and then takes at most 32 bits from it, whatever it is
-			// reading: a partition header, a whole Rice token (nearly always), or a piece of a long one - the zeros of a long
-			// unary run 32 at a time, the low bits on their own when they did not fit.  One refill site and no nested reader
-			// calls keep the loop small enough to stay in the instruction cache.
-			enum { M_HDR = 0, M_TOKEN = 1, M_LOW = 2, M_RAWHDR = 3, M_RAW = 4, M_VERB = 5 };
-			uint32_t left = 0, part = 0, k = 0, raw = 0, qacc = 0, todo = (ok && type != 0u) ? nres : 0u;
-			uint32_t mode = type == 1u ? (uint32_t)M_VERB : (uint32_t)M_HDR;
-			for(uint32_t it = 0; __any(todo != 0u ? 1 : 0); it++) {
-				if((it & 3u) == 0u && !(c.debug & 4u)) br.top_up();   // four steps take at most four words
-				if(todo != 0u) {
-					br.refill();
-					const uint32_t hi = (uint32_t)(br.buf >> 32);
-					uint32_t take; int32_t r; bool have;
-					if(mode <= M_TOKEN) {
-						// Partition header or token, straight-line for both (which one a lane is at only picks among values that
-						// are cheap to form either way).  A token that fits the upper word is the rule; the two other outcomes
-						// (32 zeros taken and the run goes on; the run ends here and the low bits come next step) fall out of
-						// the same values.
-						const bool hdr = mode == M_HDR;
-						const uint32_t lz = hi ? (uint32_t)__clz((int)hi) : 32u;
-						const bool fits = lz + k <= 31u, run_on = lz == 32u;
-						const uint32_t low = ((hi << (lz & 31u)) >> ((31u - k) & 31u)) & ((1u << (k & 31u)) - 1u);
-						const uint32_t u = ((qacc + lz) << k) | low;
-						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-						const uint32_t kh = hi >> (32u - plen);
-						const uint32_t left_h = (po == 0) ? n - order : (n >> po) - (part == 0 ? order : 0u);
-						have = !hdr && fits;
-						take = hdr ? plen : (fits ? lz + 1u + k : (run_on ? 32u : lz + 1u));
-						qacc = (hdr || fits) ? 0u : qacc + lz;
-						if(!hdr && run_on && (qacc > (1u << 26) || br.bitpos() > c.nbytes * 8u + 64u)) br.err = true;
-						// a first partition as long as the predictor order holds no residual: its header is followed by the next header
-						mode = hdr ? (kh >= esc ? (uint32_t)M_RAWHDR : (left_h ? (uint32_t)M_TOKEN : (uint32_t)M_HDR))
-						           : ((fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW);
-						left = hdr ? left_h : left;
-						k = hdr ? kh : k;
-						if(sub && hdr && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh;
-						part += hdr ? 1u : 0u;
+			// ---- the values of the subframe (residuals, or the samples of a verbatim subframe), in phases of FD_K steps.  A step
+			// refills the window once (to at least 32 bits) and takes at most 32 bits from it: a partition header, a whole Rice
+			// token (nearly always), 32 zeros of a long unary run, the end of such a run with or without its low bits, or a
+			// fixed-width field (an escape partition's width, a raw or verbatim sample).  This loop is the critical path of the
+			// whole decode (a frame is one serial chain and a lane walks it alone), so the common step - header, token, low
+			// bits - is branch-free: what a lane is at only picks among values that are cheap to form either way, the window
+			// lives in two 32-bit registers, the value is stored whether or not the step produced one (the next step overwrites
+			// it), and everything a whole wave would have to agree on is decided once per phase instead of once per step: the
+			// stream words of a phase are fetched ahead of it, errors are looked at after it, and a lane that meets a
+			// fixed-width field waits for the next phase, which then runs the general step for the whole wave.
+			enum { M_HDR = 0, M_TOKEN = 1, M_LOW = 2, M_RAWHDR = 3, M_RAW = 4, M_VERB = 5, M_IDLE = 6 };
+			const bool coded = ok && type >= 2u;
+			uint32_t todo = (ok && type != 0u) ? nres : 0u;
+			uint32_t mode = todo == 0u ? (uint32_t)M_IDLE : (type == 1u ? (uint32_t)M_VERB : (uint32_t)M_HDR);
+			uint32_t left = todo, part = 0, k = 0, raw = 0, qacc = 0;
+			const uint32_t left_first = coded ? ((po == 0u) ? n - order : (n >> po) - order) : 0u, left_other = n >> po;   // samples of the first / of any later partition
+			const uint32_t hdr_shift = 32u - plen;
+			// the window as two words; the reader object is brought up to date again after the loop
+			br.refill();
+			uint32_t whi = (uint32_t)(br.buf >> 32), wlo = (uint32_t)br.buf, wav = br.avail, widx = br.widx, nextw = br.nextw;
+			uint32_t bad = 0;
+			const uint32_t wlimit = (uint32_t)(c.nbytes >> 2) + 4u;   // word index past the end of the buffer
+			while(__any(mode != (uint32_t)M_IDLE ? 1 : 0)) {
+				// a phase takes at most FD_K words: have them in the ring before it starts (a lane short of them has room for 16 more)
+				br.widx = widx;
+				while(__any((mode != (uint32_t)M_IDLE && br.wr - widx < FD_K + 1u) ? 1 : 0)) {
+					const uint32_t ck = br.wr >> 2;
+					if(br.wr - widx + 16u <= FD_RING_WORDS) {
+						const uint4 v0 = br.load_chunk(ck), v1 = br.load_chunk(ck + 1u), v2 = br.load_chunk(ck + 2u), v3 = br.load_chunk(ck + 3u);
+						br.store_chunk(br.wr, v0); br.store_chunk(br.wr + 4u, v1); br.store_chunk(br.wr + 8u, v2); br.store_chunk(br.wr + 12u, v3);
+						br.wr += 16u;
 					}
-					else if(mode == M_LOW) {
-						const uint32_t low = k ? hi >> (32u - k) : 0u;
-						const uint32_t u = (qacc << k) | low;
-						r = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
-						take = k; qacc = 0; have = true; mode = M_TOKEN;
-					}
-					else if(mode == M_RAWHDR) { raw = hi >> 27; take = 5u; r = 0; have = false; mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR; if(sub && part - 1u < FLACAMD_SUBINFO_PARTS) sub->rice[part - 1u] = (uint8_t)(0x80u | raw); }
-					else if(mode == M_RAW) { r = raw ? (int32_t)hi >> (32u - raw) : 0; take = raw; have = true; }
-					else { r = (int32_t)hi >> (32u - bps); take = bps; have = true; }   // verbatim sample
-					br.buf <<= take; br.avail -= take;
-					if(have) {
-						if(!(c.debug & 2u)) push(r);
-						todo--;
-						if(mode != M_VERB && --left == 0u) mode = M_HDR;
-					}
-					if(br.err) { ok = false; todo = 0; }
 				}
-				if((it & (FD_K - 1u)) == FD_K - 1u && !(c.debug & 8u)) hand_over(false);
+				int32_t *pp = &pipe.buf[pb][np][lane];   // where the next value goes
+				const bool general = __any((mode == (uint32_t)M_RAWHDR || mode == (uint32_t)M_RAW) ? 1 : 0) != 0;   // escape partitions: allowed by the format, not written by the reference encoder
+				if(!general) {
+#pragma unroll 2
+					for(uint32_t step = 0; step < FD_K; step++) {
+						// refill: one more word when 32 bits or fewer are left
+						const bool need = wav <= 32u;
+						const uint32_t wsw = need ? __builtin_bswap32(nextw) : 0u;
+						const unsigned long long ins = (unsigned long long)wsw << (need ? 32u - wav : 0u);
+						whi |= (uint32_t)(ins >> 32); wlo |= (uint32_t)ins;
+						wav += need ? 32u : 0u; widx += need ? 1u : 0u;
+						nextw = br.ring[widx & (FD_RING_WORDS - 1u)][lane];
+						// header, token, or the low bits after a long run: every candidate value first, then one-level picks
+						// (nested conditionals come out of the compiler as branches over the execution mask, which cost more than
+						// all the values together)
+						const bool hdr = mode == (uint32_t)M_HDR, tok = mode == (uint32_t)M_TOKEN, lowm = mode == (uint32_t)M_LOW;
+						const uint32_t lz = fd_sel(whi != 0u, (uint32_t)__clz((int)whi), 32u);
+						const uint32_t t1 = lz + k;
+						const bool fits = t1 <= 31u, run_on = lz == 32u;
+						const uint32_t fld = __builtin_amdgcn_ubfe(whi, fd_sel(lowm, 32u - k, 31u - t1) & 31u, k);
+						const uint32_t u = (fd_sel(lowm, qacc, qacc + lz) << k) | fld;
+						const bool verb = mode == (uint32_t)M_VERB;   // a verbatim sample: bps bits as they are (1 <= bps <= 32)
+						const int32_t val = fd_sel(verb, (int32_t)whi >> (32u - bps), (int32_t)(u >> 1) ^ -(int32_t)(u & 1u));
+						const uint32_t kh = whi >> hdr_shift;
+						const uint32_t left_h = fd_sel(part == 0u, left_first, left_other);
+						const bool emit_b = (tok && fits) || lowm || verb;
+						const uint32_t emit = fd_sel(emit_b, 1u, 0u);
+						uint32_t take = fd_sel(run_on, 32u, lz + 1u);          // a token that does not fit: its zeros, and the one when it is there
+						take = fd_sel(fits, t1 + 1u, take);                     // a token that fits
+						take = fd_sel(tok, take, fd_sel(lowm, k, fd_sel(verb, bps, 0u)));
+						take = fd_sel(hdr, plen, take);
+						if(SUBINFO) { if(sub && hdr && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh; }
+						uint32_t m_hdr = fd_sel(left_h != 0u, (uint32_t)M_TOKEN, (uint32_t)M_HDR);   // a first partition as long as the predictor order holds no residual
+						m_hdr = fd_sel(kh >= esc, (uint32_t)M_RAWHDR, m_hdr);
+						const uint32_t m_tok = fd_sel(fits || run_on, (uint32_t)M_TOKEN, (uint32_t)M_LOW);
+						uint32_t m2 = fd_sel(lowm, (uint32_t)M_TOKEN, mode);
+						m2 = fd_sel(tok, m_tok, m2);
+						m2 = fd_sel(hdr, m_hdr, m2);
+						qacc = fd_sel(tok && !fits, qacc + lz, 0u);
+						left = fd_sel(hdr, left_h, left) - emit;
+						k = fd_sel(hdr, kh, k);
+						part += fd_sel(hdr, 1u, 0u);
+						todo -= emit;
+						m2 = fd_sel(emit_b && left == 0u, (uint32_t)M_HDR, m2);
+						m2 = fd_sel(emit_b && todo == 0u, (uint32_t)M_IDLE, m2);
+						mode = m2;
+						// consume
+						const unsigned long long wv = (((unsigned long long)whi << 32) | wlo) << take;   // take <= 32
+						whi = (uint32_t)(wv >> 32); wlo = (uint32_t)wv;
+						wav -= take;
+						// the value goes to the buffer either way; the place only moves on when the step produced one
+						*pp = val; pp += fd_sel(emit_b, 64, 0); np += emit;
+					}
+				}
+				else {
+					for(uint32_t step = 0; step < FD_K; step++) {
+						const bool need = wav <= 32u;
+						const uint32_t wsw = need ? __builtin_bswap32(nextw) : 0u;
+						const unsigned long long ins = (unsigned long long)wsw << (need ? 32u - wav : 0u);
+						whi |= (uint32_t)(ins >> 32); wlo |= (uint32_t)ins;
+						wav += need ? 32u : 0u; widx += need ? 1u : 0u;
+						nextw = br.ring[widx & (FD_RING_WORDS - 1u)][lane];
+						uint32_t take = 0; int32_t val = 0; bool emit = false;
+						if(mode == (uint32_t)M_HDR || mode == (uint32_t)M_TOKEN) {
+							const bool hdr = mode == (uint32_t)M_HDR;
+							const uint32_t lz = whi ? (uint32_t)__clz((int)whi) : 32u;
+							const uint32_t t1 = lz + k;
+							const bool fits = t1 <= 31u, run_on = lz == 32u;
+							const uint32_t low = __builtin_amdgcn_ubfe(whi, (31u - t1) & 31u, k);
+							const uint32_t u = ((qacc + lz) << k) | low;
+							val = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+							const uint32_t kh = whi >> hdr_shift;
+							const uint32_t left_h = part == 0u ? left_first : left_other;
+							emit = !hdr && fits;
+							take = hdr ? plen : (fits ? t1 + 1u : (run_on ? 32u : lz + 1u));
+							if(SUBINFO) { if(sub && hdr && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh; }
+							mode = hdr ? (kh >= esc ? (uint32_t)M_RAWHDR : (left_h ? (uint32_t)M_TOKEN : (uint32_t)M_HDR)) : ((fits || run_on) ? (uint32_t)M_TOKEN : (uint32_t)M_LOW);
+							qacc = (hdr || fits) ? 0u : qacc + lz;
+							left = hdr ? left_h : left;
+							k = hdr ? kh : k;
+							part += hdr ? 1u : 0u;
+						}
+						else if(mode == (uint32_t)M_RAWHDR) {
+							raw = whi >> 27; take = 5u;
+							if(SUBINFO) { if(sub && part - 1u < FLACAMD_SUBINFO_PARTS) sub->rice[part - 1u] = (uint8_t)(0x80u | raw); }
+							mode = left ? (uint32_t)M_RAW : (uint32_t)M_HDR;
+						}
+						else if(mode != (uint32_t)M_IDLE) {
+							const uint32_t wd = mode == (uint32_t)M_LOW ? k : (mode == (uint32_t)M_RAW ? raw : bps);
+							if(mode == (uint32_t)M_LOW) { const uint32_t u = (qacc << k) | (wd ? whi >> (32u - wd) : 0u); val = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u); qacc = 0; mode = (uint32_t)M_TOKEN; }
+							else val = wd ? (int32_t)whi >> (32u - wd) : 0;
+							take = wd; emit = true;
+						}
+						const unsigned long long wv = (((unsigned long long)whi << 32) | wlo) << take;
+						whi = (uint32_t)(wv >> 32); wlo = (uint32_t)wv;
+						wav -= take;
+						if(emit) {
+							*pp = val; pp += 64; np++;
+							todo--;
+							if(todo == 0u) mode = (uint32_t)M_IDLE;
+							else if(mode != (uint32_t)M_VERB && --left == 0u) mode = (uint32_t)M_HDR;
+						}
+					}
+				}
+				// a run of zeros that long is no residual (and it is what reading past the end of the buffer looks like)
+				if(mode != (uint32_t)M_IDLE && (qacc > (1u << 26) || widx > wlimit)) { bad = 1u; mode = (uint32_t)M_IDLE; }
+				hand_over(false);
 			}
+			br.buf = ((unsigned long long)whi << 32) | wlo; br.avail = wav; br.widx = widx; br.nextw = nextw;
+			if(bad) { br.err = true; ok = false; }
 			hand_over(false);
 			if(ok && type >= 2u && part == 0) { const uint32_t k0 = br.read(plen); uint32_t rb = 0; if(k0 >= esc) rb = 0x80u | br.read(5); if(sub) sub->rice[0] = (uint8_t)(rb ? rb : k0); }   // order == blocksize: the one partition is empty, its header is still there
 			if(ok && (br.err || br.bitpos() > c.nbytes * 8u)) ok = false;
@@ -506,15 +603,73 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 		uint32_t st = live ? 0u : 6u, n = 0, ch = 0, i = 0, order = 0, wasted = 0, type = 0, shift = 0, wide = 0, nres = 0, hp = 0;
 		bool in_regs = true;
 		int32_t qr[FD_REGORD], hr[FD_REGORD];
+		uint32_t qp[FD_REGORD / 2];   // the coefficients again, two to a word
+		long long bias = 3;           // what the packed sum below leaves out
 #pragma unroll
 		for(int j = 0; j < FD_REGORD; j++) { qr[j] = 0; hr[j] = 0; }
+#pragma unroll
+		for(int j = 0; j < FD_REGORD / 2; j++) qp[j] = 0;
 		int32_t *out = w.ws;
 		uint32_t p = 0;
 		for(;;) {
 			__syncthreads();
 			const uint32_t cnt = pipe.cnt[p][lane];
 			const uint32_t more = __builtin_amdgcn_readfirstlane(pipe.more[p]);
-			for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
+			// Nearly every buffer holds nothing but residuals of predicted subframes of order <= FD_REGORD, for every lane.
+			// Those are restored with the history as 16-bit halves, two taps to an instruction: a sample is
+			// x = 65536 * (x >> 16) + (x & 0xffff), the low half is taken less 32768 to make it a signed 16-bit value, so
+			//   sum q[t] * x[t] = sum q[t] * (low[t] - 32768) + 32768 * sum q[t] + 65536 * sum q[t] * high[t].
+			// Coefficients have at most 15 bits, so four taps of the first sum started from -1 cannot leave 32 bits, the sums
+			// are put together in 64 bits, and the result is the exact sum of the reference's 64-bit routine
+			// (lpc.c:1253-1296) whose low 32 bits are the sum of its 32-bit one (lpc.c:961-1251) - provided the third sum did
+			// not wrap, which it cannot while samples stay below 2^28.  That is looked at afterwards: the state is only taken
+			// over when it held for every lane, otherwise the buffer is gone through again the general way.
+			bool done = false;
+			{
+				const bool lane_fast = st == 5u && type >= 1u && in_regs && cnt <= nres && i + cnt <= n;   // verbatim samples pass as residuals of an all-zero predictor
+				if(!(c.debug & 1u) && !__any((cnt != 0u && !lane_fast) ? 1 : 0)) {
+					uint32_t hl[FD_REGORD / 2], hh[FD_REGORD / 2], mag = 0;
+#pragma unroll
+					for(int t = 0; t < FD_REGORD / 2; t++) {
+						const uint32_t a = (uint32_t)hr[2 * t], b = (uint32_t)hr[2 * t + 1];
+						hl[t] = __builtin_amdgcn_perm(b, a, 0x05040100u) ^ 0x80008000u;
+						hh[t] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+						mag |= (a ^ (uint32_t)((int32_t)a >> 31)) | (b ^ (uint32_t)((int32_t)b >> 31));
+					}
+					const int32_t *src = &pipe.buf[p][0][lane];
+					int32_t *dst = out + i;
+					for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
+						if(j < cnt) {
+							const int32_t v = src[j * 64u];
+							int32_t a0 = fd_dot2(qp[0], hl[0], -1), a1 = fd_dot2(qp[2], hl[2], -1), a2 = fd_dot2(qp[4], hl[4], -1), sh = fd_dot2(qp[0], hh[0], 0);
+							a0 = fd_dot2(qp[1], hl[1], a0); a1 = fd_dot2(qp[3], hl[3], a1); a2 = fd_dot2(qp[5], hl[5], a2);
+#pragma unroll
+							for(int t = 1; t < FD_REGORD / 2; t++) sh = fd_dot2(qp[t], hh[t], sh);
+							const long long sum = (long long)a0 + (long long)a1 + (long long)a2 + bias + ((long long)sh << 16);
+							const int32_t pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum >> shift);
+							const int32_t x = (int32_t)((uint32_t)v + (uint32_t)pred);
+#pragma unroll
+							for(int t = FD_REGORD / 2 - 1; t > 0; t--) { hl[t] = __builtin_amdgcn_alignbit(hl[t], hl[t - 1], 16); hh[t] = __builtin_amdgcn_alignbit(hh[t], hh[t - 1], 16); }
+							hl[0] = __builtin_amdgcn_perm(hl[0], (uint32_t)x ^ 0x8000u, 0x05040100u);
+							hh[0] = __builtin_amdgcn_perm(hh[0], (uint32_t)x, 0x05040302u);
+							mag |= (uint32_t)x ^ (uint32_t)(x >> 31);
+							dst[j] = (int32_t)((uint32_t)x << wasted);
+						}
+					}
+					if(!__any(mag >= (1u << 28) ? 1 : 0)) {
+#pragma unroll
+						for(int t = 0; t < FD_REGORD / 2; t++) {
+							const uint32_t lo = hl[t] ^ 0x80008000u;
+							hr[2 * t] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x05040100u);
+							hr[2 * t + 1] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x07060302u);
+						}
+						i += cnt; nres -= cnt;
+						if(cnt != 0u && nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
+						done = true;
+					}
+				}
+			}
+			if(!done) for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
 				if(j < cnt && st != 6u && !(c.debug & 1u)) {
 					const int32_t v = pipe.buf[p][j][lane];
 					if(st == 5u) {
@@ -581,6 +736,14 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 							else if(order == 2) { qr[0] = 2; qr[1] = -1; }
 							else if(order == 3) { qr[0] = 3; qr[1] = -3; qr[2] = 1; }
 							else if(order == 4) { qr[0] = 4; qr[1] = -6; qr[2] = 4; qr[3] = -1; }
+						}
+						{
+							int32_t qsum = 0;
+#pragma unroll
+							for(int t = 0; t < FD_REGORD; t++) qsum += qr[t];
+#pragma unroll
+							for(int t = 0; t < FD_REGORD / 2; t++) qp[t] = __builtin_amdgcn_perm((uint32_t)qr[2 * t + 1], (uint32_t)qr[2 * t], 0x05040100u);
+							bias = 32768ll * (long long)qsum + 3;
 						}
 						if(nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; } else st = 5u;
 					}
@@ -852,7 +1015,8 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 		return FLACAMD_E_BAD_STREAM;
 	}
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
-	hipLaunchKernelGGL(fd_decode_pipe_kernel, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
+	if(c.subinfo) hipLaunchKernelGGL(fd_decode_pipe_kernel<true>, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
+	else hipLaunchKernelGGL(fd_decode_pipe_kernel<false>, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
 	hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);

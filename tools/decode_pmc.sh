@@ -11,7 +11,7 @@ import csv, glob, collections
 f = glob.glob("$OUT/**/p_counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
-    k = r["Kernel_Name"].split("(")[0]
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
     if not k.startswith("fd_"): continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES": n[k] += 1
