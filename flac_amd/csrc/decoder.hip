@@ -51,7 +51,7 @@ struct FdWork {
 	int32_t  *ws;           // [max_frames][channels][ws_stride] subframe outputs before decorrelation
 	uint32_t *frame_of;     // [max_frames] candidate index of the r-th accepted frame
 	uint64_t *sample_off;   // [max_frames] first wide sample of the r-th accepted frame
-	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags
+	uint64_t *result;       // [8]: frames, samples, first number, bytes consumed, error flags, position of the first frame, candidates found, long-predictor flag
 	const uint16_t *crc_tab;   // [4][256] CRC-16 of a byte followed by 0..3 zero bytes
 	const uint16_t *crc_segmul;// [256] x^(8 * crc_seg_bytes * j)
 	flacamd_subframe_info *subinfo; // [max_frames][channels] when FdCfg::subinfo, by candidate
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(1024) fd_scan_offsets_kernel(FdCfg c, FdWork w
 	for(uint32_t k = 0; k < 16u; k++) { base += wave_ahead[k]; if(k < wv) base += wave_own[k]; }
 	if(i < c.nscan_wg) {
 		w.wg_off[i] = base + inc - v;
-		if(i + 1u == c.nscan_wg) w.ncand[0] = base + inc;
+		if(i + 1u == c.nscan_wg) { w.ncand[0] = base + inc; w.ncand[1] = 0u; }   // [1]: raised by the decode kernel when it met a predictor it has no room for
 	}
 }
 
@@ -349,13 +349,18 @@ struct FdPipe {
 	uint32_t more[2];
 };
 
-template<bool SUBINFO>
+// LONGPRED: with room in LDS for predictors of more than FD_REGORD taps (only streams outside the subset have them:
+// `flac --lax -l 32`).  That room is 16 KB of 53, and the LDS is what bounds the number of workgroups on a compute unit,
+// so a decode starts with the kernel without it; a lane of that kernel that meets such a predictor leaves its subframe
+// alone and raises a flag, and the host then runs the pass again with the other kernel and stays with it.
+template<bool SUBINFO, bool LONGPRED>
 __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
+	constexpr uint32_t QROWS = LONGPRED ? FD_RING : (uint32_t)FD_REGORD, HROWS = LONGPRED ? FD_RING : 1u;
 	__shared__ FdPipe pipe;
-	__shared__ int16_t s_q[FD_RING][64];    // coefficients of the subframe whose head the parser read last (parser -> restorer)
-	__shared__ int16_t s_qb[FD_RING][64];   // the restorer's copy, for orders above FD_REGORD
-	__shared__ int32_t s_h[FD_RING][64];    // the restorer's sample history, for orders above FD_REGORD
+	__shared__ int16_t s_q[QROWS][64];    // coefficients of the subframe whose head the parser read last (parser -> restorer)
+	__shared__ int16_t s_qb[HROWS][64];   // the restorer's copy, for orders above FD_REGORD
+	__shared__ int32_t s_h[HROWS][64];    // the restorer's sample history, for orders above FD_REGORD
 	__shared__ uint32_t s_ring[FD_RING_WORDS][64];
 	const uint32_t lane = threadIdx.x & 63u, role = threadIdx.x >> 6;
 	const uint32_t ci = blockIdx.x * 64u + lane;
@@ -416,7 +421,8 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					// a negative shift is never produced by the reference encoder (lpc.c:225-260) and shifting by it is undefined
 					// there; the frame still parses the same way, so go on for the sake of its length
 					shift = sh < 0 ? 0u : (uint32_t)sh;
-					for(uint32_t j = 0; j < order; j++) { br.top_up(); const int16_t qv = (int16_t)br.read_signed(prec); s_q[j][lane] = qv; if(sub) sub->q[j] = qv; }
+					for(uint32_t j = 0; j < order; j++) { br.top_up(); const int16_t qv = (int16_t)br.read_signed(prec); if(j < QROWS) s_q[j][lane] = qv; if(sub) sub->q[j] = qv; }
+					if(!LONGPRED && order > (uint32_t)FD_REGORD) w.ncand[1] = 1u;   // see above; every lane that writes writes the same
 					wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
 				}
 				const uint32_t method = br.read(2);
@@ -638,9 +644,9 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					}
 					const int32_t *src = &pipe.buf[p][0][lane];
 					int32_t *dst = out + i;
-					for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
-						if(j < cnt) {
-							const int32_t v = src[j * 64u];
+					for(uint32_t j = 0; j < cnt; j++) {   // lanes leave as their items run out; nothing in here needs the whole wave
+						{
+							const int32_t v = *src; src += 64;
 							int32_t a0 = fd_dot2(qp[0], hl[0], -1), a1 = fd_dot2(qp[2], hl[2], -1), a2 = fd_dot2(qp[4], hl[4], -1), sh = fd_dot2(qp[0], hh[0], 0);
 							a0 = fd_dot2(qp[1], hl[1], a0); a1 = fd_dot2(qp[3], hl[3], a1); a2 = fd_dot2(qp[5], hl[5], a2);
 #pragma unroll
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 							hl[0] = __builtin_amdgcn_perm(hl[0], (uint32_t)x ^ 0x8000u, 0x05040100u);
 							hh[0] = __builtin_amdgcn_perm(hh[0], (uint32_t)x, 0x05040302u);
 							mag |= (uint32_t)x ^ (uint32_t)(x >> 31);
-							dst[j] = (int32_t)((uint32_t)x << wasted);
+							*dst++ = (int32_t)((uint32_t)x << wasted);
 						}
 					}
 					if(!__any(mag >= (1u << 28) ? 1 : 0)) {
@@ -694,6 +700,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 								for(int t = FD_REGORD - 1; t > 0; t--) hr[t] = hr[t - 1];
 								hr[0] = x;
 							}
+							else if(!LONGPRED) x = v;   // not this kernel's: the pass is run again
 							else {
 								if(wide) { long long sum = 0; for(uint32_t t = 0; t < order; t++) sum += (long long)s_qb[t][lane] * (long long)s_h[(hp - 1u - t) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)v + (uint32_t)(int32_t)(sum >> shift)); }
 								else { uint32_t sum = 0; for(uint32_t t = 0; t < order; t++) sum += (uint32_t)(int32_t)s_qb[t][lane] * (uint32_t)s_h[(hp - 1u - t) & (FD_RING - 1u)][lane]; x = (int32_t)((uint32_t)v + (uint32_t)((int32_t)sum >> shift)); }
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					}
 					else if(st == 2u) {
 						if(i < n) out[i] = (int32_t)((uint32_t)v << wasted);
-						s_h[hp & (FD_RING - 1u)][lane] = v; hp++;
+						if(LONGPRED) { s_h[hp & (FD_RING - 1u)][lane] = v; hp++; }
 #pragma unroll
 						for(int t = FD_REGORD - 1; t > 0; t--) hr[t] = hr[t - 1];
 						hr[0] = v;
@@ -727,7 +734,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						in_regs = order <= (uint32_t)FD_REGORD;
 						if(type == 3u) {
 							// the parser left the coefficients in its LDS column; it will not touch them before the next subframe head
-							for(uint32_t t = 0; t < order; t++) s_qb[t][lane] = s_q[t][lane];
+							if(LONGPRED) for(uint32_t t = 0; t < order; t++) s_qb[t][lane] = s_q[t][lane];
 #pragma unroll
 							for(int t = 0; t < FD_REGORD; t++) qr[t] = ((uint32_t)t < order) ? (int32_t)s_q[t][lane] : 0;
 						}
@@ -878,6 +885,7 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 		w.result[4] = err;
 		w.result[5] = nframes ? w.cand_pos[w.frame_of[0]] : 0;
 		w.result[6] = ncand_raw;
+		w.result[7] = w.ncand[1];
 	}
 }
 
@@ -928,6 +936,7 @@ struct flacamd_decoder {
 	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
 	uint32_t last_ncand, last_nframes, last_damage;
 	void *d_subinfo;
+	int long_predictors;   // the stream has predictors of more than FD_REGORD taps: the kernel with room for them is used
 };
 
 #define FD_TRY(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { snprintf(fd_last_error, sizeof fd_last_error, "%s: %s", #call, hipGetErrorString(e_)); fa_set_last_error(fd_last_error); return e_ == hipErrorOutOfMemory ? FLACAMD_E_OUT_OF_MEMORY : FLACAMD_E_DEVICE; } } while(0)
@@ -1015,15 +1024,26 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 		return FLACAMD_E_BAD_STREAM;
 	}
 	if(ncand > c.max_frames) return FLACAMD_E_CAPACITY;
-	if(c.subinfo) hipLaunchKernelGGL(fd_decode_pipe_kernel<true>, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
-	else hipLaunchKernelGGL(fd_decode_pipe_kernel<false>, dim3((ncand + 63u) / 64u), dim3(128), 0, st, bytes, c, d->work);
-	hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
-	hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
-	hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);
-	FD_TRY(hipGetLastError());
 	uint64_t res[8];
-	FD_TRY(hipMemcpyAsync(res, d->work.result, sizeof res, hipMemcpyDeviceToHost, st));
-	FD_TRY(hipStreamSynchronize(st));
+	for(;;) {
+		const dim3 grid((ncand + 63u) / 64u), block(128);
+		if(d->long_predictors) {
+			if(c.subinfo) hipLaunchKernelGGL((fd_decode_pipe_kernel<true, true>), grid, block, 0, st, bytes, c, d->work);
+			else hipLaunchKernelGGL((fd_decode_pipe_kernel<false, true>), grid, block, 0, st, bytes, c, d->work);
+		}
+		else {
+			if(c.subinfo) hipLaunchKernelGGL((fd_decode_pipe_kernel<true, false>), grid, block, 0, st, bytes, c, d->work);
+			else hipLaunchKernelGGL((fd_decode_pipe_kernel<false, false>), grid, block, 0, st, bytes, c, d->work);
+		}
+		hipLaunchKernelGGL(fd_crc_kernel, dim3(ncand), dim3(FD_CRC_THREADS), 0, st, bytes, c, d->work);
+		hipLaunchKernelGGL(fd_chain_kernel, dim3(1), dim3(1024), 0, st, c, d->work);
+		hipLaunchKernelGGL(fd_finalize_kernel, dim3(ncand), dim3(256), 0, st, c, d->work, d_pcm);
+		FD_TRY(hipGetLastError());
+		FD_TRY(hipMemcpyAsync(res, d->work.result, sizeof res, hipMemcpyDeviceToHost, st));
+		FD_TRY(hipStreamSynchronize(st));
+		if(!res[7] || d->long_predictors) break;
+		d->long_predictors = 1;   // a predictor of more than FD_REGORD taps was met: once more, with the kernel that has room for them
+	}
 	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
 	if(res[4] & 8u) return FLACAMD_E_CAPACITY;
 	if(c.tolerant ? (res[4] & ~(uint64_t)3) != 0 : res[4] != 0) return FLACAMD_E_BAD_STREAM;
