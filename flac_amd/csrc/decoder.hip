@@ -23,7 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define FD_SCAN_BYTES 4096u   // bytes scanned per workgroup
+#define FD_SCAN_BYTES 4096u   // bytes of a scan tile (16 to a thread)
 
 struct FdCfg {
 	uint32_t channels, bps, max_bs, max_frames;
@@ -114,43 +114,86 @@ __device__ bool fd_parse_header(const uint8_t *__restrict__ b, uint64_t nbytes, 
 
 // ---- candidate scan: count, offsets, ordered write
 
+// A workgroup takes FD_SCAN_TILES tiles of FD_SCAN_BYTES one after the other in the same instructions (every tile's load is
+// in flight before the first is looked at, and there are a quarter as many waves to start); the bookkeeping stays per tile.
+#define FD_SCAN_TILES 4u
 template<bool WRITE>
 __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict__ b, FdCfg c, FdWork w)
 {
-	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_wave[FD_SCAN_TILES][4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	const uint64_t p0 = (uint64_t)blockIdx.x * FD_SCAN_BYTES + (uint64_t)tid * 16u;
-	uint32_t mask = 0;
-	const uint64_t ti = (uint64_t)blockIdx.x * 256u + tid;
-	if(WRITE) mask = w.scan_mask[ti];   // the counting pass left every thread's findings: the bytes are not read twice
+	uint32_t mask[FD_SCAN_TILES];
+	uint64_t p0[FD_SCAN_TILES];
+#pragma unroll
+	for(uint32_t q = 0; q < FD_SCAN_TILES; q++) p0[q] = ((uint64_t)blockIdx.x * FD_SCAN_TILES + q) * FD_SCAN_BYTES + (uint64_t)tid * 16u;
+	if(WRITE) {
+		// the counting pass left every thread's findings: the bytes are not read twice
+#pragma unroll
+		for(uint32_t q = 0; q < FD_SCAN_TILES; q++) { const uint32_t tile = blockIdx.x * FD_SCAN_TILES + q; mask[q] = tile < c.nscan_wg ? w.scan_mask[(uint64_t)tile * 256u + tid] : 0u; }
+	}
 	else {
 		// the thread's 16 bytes and the one after them in registers (one 16-byte load; the buffer is 16-byte aligned): positions
 		// that hold the two sync bytes are rare, only those go on to the header check
-		uint32_t wd[4] = {0, 0, 0, 0}, nxt = 0;
-		if(p0 + 16u <= c.nbytes) { const uint4 v = *(const uint4*)(b + p0); wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
-		else for(uint32_t k = 0; k < 16u; k++) if(p0 + k < c.nbytes) wd[k >> 2] |= (uint32_t)b[p0 + k] << (8u * (k & 3u));
-		if(p0 + 16u < c.nbytes) nxt = b[p0 + 16u];
+		uint32_t wd[FD_SCAN_TILES][4], nxt[FD_SCAN_TILES];
 #pragma unroll
-		for(uint32_t k = 0; k < 16; k++) {
-			const uint32_t b0 = (wd[k >> 2] >> (8u * (k & 3u))) & 0xffu;
-			const uint32_t b1 = k < 15u ? (wd[(k + 1u) >> 2] >> (8u * ((k + 1u) & 3u))) & 0xffu : nxt;
-			if(b0 == 0xffu && (b1 & 0xfeu) == 0xf8u && p0 + k + 1u < c.nbytes) { FdHeader h; if(fd_parse_header(b, c.nbytes, p0 + k, c, h)) mask |= 1u << k; }
+		for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
+			wd[q][0] = wd[q][1] = wd[q][2] = wd[q][3] = 0; nxt[q] = 0;
+			if(p0[q] + 16u <= c.nbytes) { const uint4 v = *(const uint4*)(b + p0[q]); wd[q][0] = v.x; wd[q][1] = v.y; wd[q][2] = v.z; wd[q][3] = v.w; }
+			else for(uint32_t k = 0; k < 16u; k++) if(p0[q] + k < c.nbytes) wd[q][k >> 2] |= (uint32_t)b[p0[q] + k] << (8u * (k & 3u));
 		}
-		w.scan_mask[ti] = (uint16_t)mask;
-	}
-	const uint32_t cnt = (uint32_t)__popc(mask);
-	// in-workgroup exclusive scan of the per-thread counts
-	uint32_t inc = cnt;
+		// the byte after: the neighbouring lane has it, only the last lane of a wave fetches it
 #pragma unroll
-	for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
-	if(lane == 63u) s_wave[wv] = inc;
+		for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
+			const uint32_t nb = (uint32_t)__shfl_down((int)wd[q][0], 1, 64) & 0xffu;
+			nxt[q] = lane == 63u ? (p0[q] + 16u < c.nbytes ? (uint32_t)b[p0[q] + 16u] : 0u) : nb;
+		}
+#pragma unroll
+		for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
+			// which of the 16 bytes can be 0xff: the zero-byte test on the complement marks every such byte (and now and then
+			// one above it, which the comparison below sorts out); about one thread in sixteen has any, so the loop runs once
+			// or twice for a wave instead of sixteen times
+			uint32_t m = 0, found = 0;
+#pragma unroll
+			for(uint32_t j = 0; j < 4; j++) {
+				const uint32_t v = ~wd[q][j];
+				const uint32_t x = (((v - 0x01010101u) & ~v) >> 7) & 0x01010101u;
+				m |= ((x | (x >> 7) | (x >> 14) | (x >> 21)) & 15u) << (4u * j);
+			}
+			while(m) {
+				const uint32_t k = (uint32_t)__builtin_ctz(m);
+				m &= m - 1u;
+				const uint32_t j = k >> 2;
+				const uint32_t lo = j == 0u ? wd[q][0] : (j == 1u ? wd[q][1] : (j == 2u ? wd[q][2] : wd[q][3]));
+				const uint32_t hi = j == 0u ? wd[q][1] : (j == 1u ? wd[q][2] : (j == 2u ? wd[q][3] : nxt[q]));
+				const uint32_t two = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8u * (k & 3u)));
+				if((two & 0xfeffu) == 0xf8ffu && p0[q] + k + 1u < c.nbytes) { FdHeader h; if(fd_parse_header(b, c.nbytes, p0[q] + k, c, h)) found |= 1u << k; }
+			}
+			mask[q] = found;
+			const uint32_t tile = blockIdx.x * FD_SCAN_TILES + q;
+			if(tile < c.nscan_wg) w.scan_mask[(uint64_t)tile * 256u + tid] = (uint16_t)found;
+		}
+	}
+	// in-workgroup exclusive scan of the per-thread counts, tile by tile
+	uint32_t cnt[FD_SCAN_TILES], inc[FD_SCAN_TILES];
+#pragma unroll
+	for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
+		cnt[q] = (uint32_t)__popc(mask[q]); inc[q] = cnt[q];
+#pragma unroll
+		for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc[q], o, 64); if(lane >= (uint32_t)o) inc[q] += t; }
+		if(lane == 63u) s_wave[q][wv] = inc[q];
+	}
 	__syncthreads();
-	uint32_t pre = 0;
-	for(uint32_t i = 0; i < wv; i++) pre += s_wave[i];
-	if(!WRITE) { if(tid == 255u) w.wg_count[blockIdx.x] = pre + inc; }
-	else {
-		uint32_t at = w.wg_off[blockIdx.x] + pre + inc - cnt;
-		for(uint32_t k = 0; k < 16; k++) if(mask & (1u << k)) { if(at < c.max_frames) w.cand_pos[at] = p0 + k; at++; }
+#pragma unroll
+	for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
+		const uint32_t tile = blockIdx.x * FD_SCAN_TILES + q;
+		if(tile >= c.nscan_wg) break;
+		uint32_t pre = 0;
+		for(uint32_t i = 0; i < wv; i++) pre += s_wave[q][i];
+		if(!WRITE) { if(tid == 255u) w.wg_count[tile] = pre + inc[q]; }
+		else if(cnt[q]) {
+			uint32_t at = w.wg_off[tile] + pre + inc[q] - cnt[q];
+			for(uint32_t k = 0; k < 16; k++) if(mask[q] & (1u << k)) { if(at < c.max_frames) w.cand_pos[at] = p0[q] + k; at++; }
+		}
 	}
 }
 
@@ -839,41 +882,68 @@ __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *_
 	}
 }
 
-// Accept CRC-valid candidates, check that they tile the range, number them, prefix-sum samples
+// Accept CRC-valid candidates, check that they tile the range, number them, prefix-sum samples.  One workgroup walks the
+// candidates FD_CHAIN_PER to a thread and 1024 threads at a time (every load of a round is in flight before the first is
+// used); what goes from one thread to the next is a count, a sum, and where the last accepted frame before it ended.
+#define FD_CHAIN_PER 4u
 __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 {
-	__shared__ unsigned long long wave_a[16], wave_b[16];
-	__shared__ unsigned long long carry_a, carry_b;
+	__shared__ unsigned long long wave_a[16], wave_b[16], wave_end[16];
+	__shared__ uint32_t wave_has[16];
+	__shared__ unsigned long long carry_a, carry_b, carry_end;
+	__shared__ uint32_t carry_has;
 	__shared__ uint32_t s_err;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint32_t ncand_raw = w.ncand[0];
 	const uint32_t ncand = ncand_raw < c.max_frames ? ncand_raw : c.max_frames;
-	if(tid == 0) { carry_a = 0; carry_b = 0; s_err = ncand_raw > c.max_frames ? 4u : 0u; }
+	if(tid == 0) { carry_a = 0; carry_b = 0; carry_end = 0; carry_has = 0; s_err = ncand_raw > c.max_frames ? 4u : 0u; }
 	__syncthreads();
-	for(uint32_t base = 0; base < ncand; base += 1024) {
-		const uint32_t i = base + tid;
-		const bool valid = i < ncand && (w.cand_info[i] & 3u) == 3u;
-		const unsigned long long va = valid ? 1u : 0u, vb = valid ? w.cand_bs[i] : 0u;
-		unsigned long long ia = va, ib = vb;
+	for(uint32_t base = 0; base < ncand; base += 1024u * FD_CHAIN_PER) {
+		const uint32_t i0 = base + tid * FD_CHAIN_PER;
+		uint32_t info[FD_CHAIN_PER], bs[FD_CHAIN_PER];
+		unsigned long long pos[FD_CHAIN_PER], end[FD_CHAIN_PER];
+#pragma unroll
+		for(uint32_t k = 0; k < FD_CHAIN_PER; k++) {
+			const bool in = i0 + k < ncand;
+			info[k] = in ? w.cand_info[i0 + k] : 0u; bs[k] = in ? w.cand_bs[i0 + k] : 0u;
+			pos[k] = in ? w.cand_pos[i0 + k] : 0u; end[k] = in ? w.cand_end[i0 + k] : 0u;
+		}
+		// the thread's own candidates: how many are frames, their samples, whether they follow one another, and the ends of the run
+		uint32_t cnt = 0, breaks = 0; unsigned long long sum = 0, first_pos = 0, last_end = 0;
+#pragma unroll
+		for(uint32_t k = 0; k < FD_CHAIN_PER; k++) if((info[k] & 3u) == 3u) {
+			if(cnt == 0) first_pos = pos[k]; else if(pos[k] != last_end) breaks = 1u;
+			last_end = end[k]; cnt++; sum += bs[k];
+		}
+		unsigned long long ia = cnt, ib = sum;
 #pragma unroll
 		for(int o = 1; o < 64; o <<= 1) {
 			const unsigned long long ta = (unsigned long long)__shfl_up((long long)ia, o, 64), tb = (unsigned long long)__shfl_up((long long)ib, o, 64);
 			if(lane >= (uint32_t)o) { ia += ta; ib += tb; }
 		}
+		// where the last frame ahead of this thread ended: the nearest lane below that has one, else an earlier wave, else the round before
+		const unsigned long long have = __ballot(cnt != 0u);
+		const unsigned long long below = have & ((1ull << lane) - 1ull);
+		const int src = below ? 63 - __clzll((long long)below) : 0;
+		const unsigned long long end_in_wave = (unsigned long long)__shfl((long long)last_end, src, 64);
 		if(lane == 63u) { wave_a[wv] = ia; wave_b[wv] = ib; }
+		const unsigned long long end_of_wave = (unsigned long long)__shfl((long long)last_end, have ? 63 - __clzll((long long)have) : 0, 64);   // every lane takes part in the exchange
+		if(lane == 0u) { wave_has[wv] = have ? 1u : 0u; wave_end[wv] = end_of_wave; }
 		__syncthreads();
-		unsigned long long pa = carry_a, pb = carry_b;
-		for(uint32_t k = 0; k < wv; k++) { pa += wave_a[k]; pb += wave_b[k]; }
-		if(valid) { const uint32_t r = (uint32_t)(pa + ia - 1u); w.frame_of[r] = i; w.sample_off[r] = pb + ib - vb; }
+		unsigned long long pa = carry_a, pb = carry_b, prev_end = carry_end; uint32_t prev_has = carry_has;
+		for(uint32_t k = 0; k < wv; k++) { pa += wave_a[k]; pb += wave_b[k]; if(wave_has[k]) { prev_has = 1u; prev_end = wave_end[k]; } }
+		if(below) { prev_has = 1u; prev_end = end_in_wave; }
+		if(cnt) {
+			if(breaks || (prev_has && first_pos != prev_end)) atomicOr(&s_err, 1u);
+			uint32_t r = (uint32_t)(pa + ia - cnt); unsigned long long so = pb + ib - sum;
+#pragma unroll
+			for(uint32_t k = 0; k < FD_CHAIN_PER; k++) if((info[k] & 3u) == 3u) { w.frame_of[r] = i0 + k; w.sample_off[r] = so; r++; so += bs[k]; }
+		}
 		__syncthreads();
-		if(tid == 1023u) { carry_a = pa + ia; carry_b = pb + ib; }
+		if(tid == 1023u) { carry_a = pa + ia; carry_b = pb + ib; if(cnt) { carry_has = 1u; carry_end = last_end; } else if(prev_has) { carry_has = 1u; carry_end = prev_end; } }
 		__syncthreads();
 	}
 	const uint32_t nframes = (uint32_t)carry_a;
-	__syncthreads();
-	// contiguity: frame r+1 starts where frame r ends
-	for(uint32_t r = tid; r + 1 < nframes; r += 1024) if(w.cand_end[w.frame_of[r]] != w.cand_pos[w.frame_of[r + 1]]) atomicOr(&s_err, 1u);
-	__syncthreads();
 	if(tid == 0) {
 		w.result[0] = nframes; w.result[1] = carry_b;
 		w.result[2] = nframes ? w.cand_num[w.frame_of[0]] : 0;
@@ -1012,9 +1082,9 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	{ static const uint32_t dbg = getenv("FLACAMD_DECODE_DEBUG") ? (uint32_t)strtoul(getenv("FLACAMD_DECODE_DEBUG"), 0, 0) : 0u; c.debug = dbg; }
 	c.nbytes = nbytes; c.nscan_wg = (uint32_t)((nbytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES); c.pcm_format = (uint32_t)pcm_format; c.pcm_cap = pcm_cap_samples;
 	const uint8_t *bytes = (const uint8_t*)d_bytes;
-	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3((c.nscan_wg + FD_SCAN_TILES - 1u) / FD_SCAN_TILES), dim3(256), 0, st, bytes, c, d->work);
 	hipLaunchKernelGGL(fd_scan_offsets_kernel, dim3((c.nscan_wg + 1023u) / 1024u), dim3(1024), 0, st, c, d->work);
-	hipLaunchKernelGGL(fd_scan_kernel<true>, dim3(c.nscan_wg), dim3(256), 0, st, bytes, c, d->work);
+	hipLaunchKernelGGL(fd_scan_kernel<true>, dim3((c.nscan_wg + FD_SCAN_TILES - 1u) / FD_SCAN_TILES), dim3(256), 0, st, bytes, c, d->work);
 	uint32_t ncand = 0;
 	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
 	FD_TRY(hipStreamSynchronize(st));
