@@ -201,7 +201,7 @@ def config_c4(dev, local, base_pcm, hours=5):
     dec = engine.Decoder(2, 16, FRAME, int(F * 1.25) + 64, total + 64, device=local)
     d_back = torch.empty((n, 2), dtype=torch.int16, device=dev)
     res = {"workload": "decode of a %.2f GB flac -8 stream (%d h of 16/44.1 stereo, %d frames) resident in HBM, one pass, one GPU" % (total / 1e9, hours, F), "by_batch": {}}
-    for h in sorted({1, 2, 4, hours}):
+    for h in sorted({1, 2, 4, 8, hours}):
         if h > hours:
             continue
         fr = min(F, (h * 3600 * RATE + FRAME - 1) // FRAME)
@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (C3, C4, C5)")
     ap.add_argument("--clips", type=int, default=10000)
     ap.add_argument("--c3-seconds", type=int, default=600)
-    ap.add_argument("--c4-hours", type=int, default=5)
+    ap.add_argument("--c4-hours", type=int, default=8)
     args = ap.parse_args()
 
     import torch

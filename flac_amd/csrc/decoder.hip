@@ -432,6 +432,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 		const uint32_t n = h.blocksize;
 		BitReader br; br.init(bytes, c.nbytes, ok ? pos + h.hdr_bytes : 0, s_ring, lane);
 		uint32_t ex = 0;
+		uint4 pf0 = make_uint4(0u, 0u, 0u, 0u), pf1 = pf0, pf2 = pf0, pf3 = pf0; uint32_t pf_at = 0; bool pf_valid = false;   // 64 bytes of the stream on their way to the ring
 		if(ok) push((int32_t)n);
 		for(uint32_t ch = 0; ch < c.channels; ch++) {
 			// ---- head of the subframe (per lane, no barrier inside)
@@ -504,8 +505,15 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 			uint32_t bad = 0;
 			const uint32_t wlimit = (uint32_t)(c.nbytes >> 2) + 4u;   // word index past the end of the buffer
 			while(__any(mode != (uint32_t)M_IDLE ? 1 : 0)) {
-				// a phase takes at most FD_K words: have them in the ring before it starts (a lane short of them has room for 16 more)
+				// A phase takes at most FD_K words and they have to be in the ring before it starts.  16 more are asked of memory a
+				// phase ahead and go into the ring at the start of the next phase that has room for them, so their latency passes
+				// behind 32 steps; a lane that still starts a phase short of FD_K + 1 words (it took more than 16 a phase: verbatim
+				// samples of more than 16 bits) fetches on the spot.
 				br.widx = widx;
+				if(pf_valid && pf_at == br.wr && br.wr - widx + 16u <= FD_RING_WORDS) {
+					br.store_chunk(br.wr, pf0); br.store_chunk(br.wr + 4u, pf1); br.store_chunk(br.wr + 8u, pf2); br.store_chunk(br.wr + 12u, pf3);
+					br.wr += 16u; pf_valid = false;
+				}
 				while(__any((mode != (uint32_t)M_IDLE && br.wr - widx < FD_K + 1u) ? 1 : 0)) {
 					const uint32_t ck = br.wr >> 2;
 					if(br.wr - widx + 16u <= FD_RING_WORDS) {
@@ -513,6 +521,12 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						br.store_chunk(br.wr, v0); br.store_chunk(br.wr + 4u, v1); br.store_chunk(br.wr + 8u, v2); br.store_chunk(br.wr + 12u, v3);
 						br.wr += 16u;
 					}
+				}
+				if(pf_at != br.wr) pf_valid = false;   // the ring moved on without the words on their way
+				if(!pf_valid && mode != (uint32_t)M_IDLE) {
+					const uint32_t ck = br.wr >> 2;
+					pf0 = br.load_chunk(ck); pf1 = br.load_chunk(ck + 1u); pf2 = br.load_chunk(ck + 2u); pf3 = br.load_chunk(ck + 3u);
+					pf_at = br.wr; pf_valid = true;
 				}
 				int32_t *pp = &pipe.buf[pb][np][lane];   // where the next value goes
 				const bool general = __any((mode == (uint32_t)M_RAWHDR || mode == (uint32_t)M_RAW) ? 1 : 0) != 0;   // escape partitions: allowed by the format, not written by the reference encoder
