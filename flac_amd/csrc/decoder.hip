@@ -700,6 +700,11 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						mag |= (a ^ (uint32_t)((int32_t)a >> 31)) | (b ^ (uint32_t)((int32_t)b >> 31));
 					}
 					const int32_t *src = &pipe.buf[p][0][lane];
+					// Every lane writes its own row, so a store instruction touches 64 cache lines whatever its width: samples are
+					// kept until four that share an aligned 16 bytes are together and go out in one store.  Samples whose four
+					// began in an earlier buffer go out singly as they come, those whose four end in a later one after the loop.
+					int32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+					uint32_t pm = i & 3u;             // place of the next sample within its four
 					int32_t *dst = out + i;
 					for(uint32_t j = 0; j < cnt; j++) {   // lanes leave as their items run out; nothing in here needs the whole wave
 						{
@@ -716,8 +721,17 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 							hl[0] = __builtin_amdgcn_perm(hl[0], (uint32_t)x ^ 0x8000u, 0x05040100u);
 							hh[0] = __builtin_amdgcn_perm(hh[0], (uint32_t)x, 0x05040302u);
 							mag |= (uint32_t)x ^ (uint32_t)(x >> 31);
-							*dst++ = (int32_t)((uint32_t)x << wasted);
+							const int32_t y = (int32_t)((uint32_t)x << wasted);
+							o0 = o1; o1 = o2; o2 = o3; o3 = y;
+							if(pm > j) *dst = y;                                                   // its four began before this buffer
+							else if(pm == 3u) *(int4*)(dst - 3) = make_int4(o0, o1, o2, o3);       // (j >= 3 here: the four are all of this buffer)
+							dst++; pm = (pm + 1u) & 3u;
 						}
+					}
+					if(pm <= cnt) {   // pm samples of an unfinished four (when it began in this buffer)
+						if(pm >= 1u) dst[-1] = o3;
+						if(pm >= 2u) dst[-2] = o2;
+						if(pm >= 3u) dst[-3] = o1;
 					}
 					if(!__any(mag >= (1u << 28) ? 1 : 0)) {
 #pragma unroll
