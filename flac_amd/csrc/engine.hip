@@ -20,6 +20,8 @@
 
 extern "C" {
 void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+int fa_prep_fast_ok(const void *pcm, const FaCfg *c);
+int fa_search_fast_ok(const void *pcm, const FaCfg *c);
 void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
 void fa_launch_model(const FaCfg *c, const FaWork *w, hipStream_t st);
 size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg);
@@ -277,7 +279,8 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		o_ncand = take(G * 4), o_cand = take((size_t)c.max_cand * c.cand_stride * G * 4 + 16),
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
 		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_fshift = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
-		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u);
+		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u),
+		o_fps = take((p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? G * 320u * 4u : 0u);   // only the 16-bit stereo kernels use it
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
 	if(he != hipSuccess) { rc = hip_fail(he, "hipMalloc(arena)"); free(e); return rc; }
@@ -287,6 +290,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
 	w.xs_spill = (int32_t*)(b + o_spill);
+	w.fixed_psum = (p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? (uint32_t*)(b + o_fps) : (uint32_t*)0;
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.frame_shift = (uint32_t*)(b + o_fshift); w.window = (const float*)(b + o_window);
 
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
@@ -410,8 +414,9 @@ static int repack_long(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, vo
 }
 
 // The stages of one batch on stream st, nothing else: no readback, no synchronisation.
-static int enqueue_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, hipStream_t st)
+static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, hipStream_t st)
 {
+	FaCfg c = c_in;
 	e->last_F = c.F; e->last_G = c.G;
 
 	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
@@ -426,6 +431,8 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, 
 		fa_launch_autoc(d_pcm, &c, &e->work, e->side);
 		HIP_TRY(hipEventRecord(e->ev_join, e->side));
 	}
+	// the fixed predictors' partition sums are a by-product of the preparation kernel's difference pass: the search kernel need not redo it
+	c.fixed_psum = (e->work.fixed_psum && fa_prep_fast_ok(d_pcm, &c) && fa_search_fast_ok(d_pcm, &c) && !(c.debug & 0x40000u)) ? 1u : 0u;
 	fa_launch_prep(d_pcm, &c, &e->work, st);
 	if(tm) (void)hipEventRecord(e->ev[1], st);
 	if(fork) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));

@@ -46,6 +46,7 @@ struct FaCfg {
 	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
 	uint32_t G;               // F * nsig
 	uint32_t debug;           // development ablation switches (FLACAMD_DEBUG), 0 in production
+	uint32_t fixed_psum;      // the 16-bit stereo preparation kernel leaves the fixed predictors' |residual| sums per finest partition (FaWork::fixed_psum) and the register-resident search kernel takes them from there
 };
 
 // Candidate header word written by the model kernel, read by the search kernel.
@@ -100,6 +101,7 @@ struct FaWork {
 	uint8_t  *wasted;      // [G]
 	uint8_t  *is_const;    // [G] bit 0: all samples equal; bit 1: every sample fits 16 bits (set by the 16-bit stereo preparation kernel only)
 	uint64_t *fixed_err;   // [5][G]
+	uint32_t *fixed_psum;  // [G][5][64] sum of |k-th difference| over the residual samples of each finest partition, before the wasted-bit shift (FaCfg::fixed_psum)
 	// autocorrelation
 	float    *autoc;       // [num_apod][lag][G]
 	// model

@@ -106,8 +106,10 @@ struct PrepFastShared { unsigned long long err[4][5]; uint32_t orv[4], ne[4]; };
 __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
 {
 	__shared__ PrepFastShared sh;
+	__shared__ uint32_t s_fps[4][5][64];   // per signal and difference order: sums over the finest partitions (FaCfg::fixed_psum)
 	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t n = fa_frame_len(c, w, f);
+	if(c.fixed_psum) for(uint32_t t = tid; t < 4u * 5u * 64u; t += 256u) (&s_fps[0][0][0])[t] = 0u;
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
 	const uint32_t i0 = tid * PP_CH;
 	if(tid < 20u) sh.err[tid / 5u][tid % 5u] = 0;
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 				}
 				// bit 0: differs from the first sample somewhere; bit 1 (side signal of 16-bit channels, nominally 17 bits): a sample outside the 16-bit range
 				d = (diff ? 1u : 0u) | ((s == 3 && (mag >> 15)) ? 2u : 0u);
+				uint32_t r0 = e0, r1 = e1, r2 = e2, r3 = e3, r4 = e4;   // the same sums over the samples that have a residual: i >= k for order k
 				if(tid == 0) {
 					// samples 0..3 of the frame: history is zero, so d_k(q) is the k-th difference of (0, 0, 0, 0, x0, x1, x2, x3)
 					const uint32_t s0 = (uint32_t)x[4], s1 = (uint32_t)x[5], s2 = (uint32_t)x[6], s3 = (uint32_t)x[7];
@@ -183,6 +186,17 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 					e2 -= mg(f2[0]) + mg(f2[1]) + mg(f2[2]) + mg(f2[3]);
 					e3 -= mg(f3[0]) + mg(f3[1]) + mg(f3[2]) + mg(f3[3]);
 					e4 -= mg(f4[0]) + mg(f4[1]) + mg(f4[2]) + mg(f4[3]);
+					r1 -= mg(f1[0]); r2 -= mg(f2[0]) + mg(f2[1]); r3 -= mg(f3[0]) + mg(f3[1]) + mg(f3[2]); r4 -= mg(f4[0]) + mg(f4[1]) + mg(f4[2]) + mg(f4[3]);
+				}
+				if(c.fixed_psum) {
+					// finest partition of this thread's 16 samples (stream_encoder.c:2934-2941 for a full block; the search kernel
+					// only takes these sums when that partition is a whole number of threads)
+					const uint32_t tz = (uint32_t)__ffs((int)n) - 1u, maxpo = tz < c.max_po ? tz : c.max_po;
+					const uint32_t part = i0 / (n >> maxpo);
+					if(part < 64u) {
+						atomicAdd(&s_fps[s][0][part], r0); atomicAdd(&s_fps[s][1][part], r1); atomicAdd(&s_fps[s][2][part], r2);
+						atomicAdd(&s_fps[s][3][part], r3); atomicAdd(&s_fps[s][4][part], r4);
+					}
 				}
 			}
 		}
@@ -222,6 +236,10 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 	if((lane & 7u) == 0) { const uint32_t idx = lane >> 3; if(idx < 4u) atomicOr(&sh.orv[idx], vo[0]); else atomicOr(&sh.ne[idx - 4u], vo[0]); }
 	__syncthreads();
 
+	if(c.fixed_psum && whole) {
+		uint32_t *dst = w.fixed_psum + (size_t)f * c.nsig * 320u;
+		for(uint32_t t = tid; t < c.nsig * 320u; t += 256u) dst[t] = (&s_fps[0][0][0])[t];   // signal-major in both
+	}
 	if(tid < c.nsig * 5u) {
 		const uint32_t s = tid / 5u, k = tid - s * 5u, g = f * c.nsig + s;
 		const uint32_t all = sh.orv[s];
@@ -233,10 +251,15 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 	}
 }
 
+// 16-bit stereo (left/right, plus mid/side when analysed) with blocks of at most 256 x 16 samples
+extern "C" int fa_prep_fast_ok(const void *pcm, const FaCfg *c)
+{
+	return c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && c->N <= 256u * PP_CH && (c->N % 4u) == 0 && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x2000u);
+}
+
 extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
-	// 16-bit stereo (left/right, plus mid/side when analysed) with blocks of at most 256 x 16 samples
-	if(c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && c->N <= 256u * PP_CH && (c->N % 4u) == 0 && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x2000u)) {
+	if(fa_prep_fast_ok(pcm, c)) {
 		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
 		return;
 	}

@@ -143,6 +143,15 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				cqp[tt] = pack_lo16(q0, q1);
 			}
 		}
+		// the fixed predictors' partition sums, when the preparation stage left them: entry t and t + 256 of the signal's
+		// [5][64] table (asked for here, used after the barrier)
+		uint32_t fps_a = 0, fps_b = 0;
+		const bool take_fps = c.fixed_psum && cb == 0u;
+		if(take_fps) {
+			const uint32_t *fp = w.fixed_psum + (size_t)g * 320u;
+			fps_a = fp[tid];
+			if(tid < 64u) fps_b = fp[256u + tid];
+		}
 		// ---- this thread's samples i0 - HIST .. i0 + SF_CH - 1, fetched anew for every candidate group (there is
 		// one group unless a precision search multiplies the candidates) so that they do not occupy
 		// registers during the evaluation phase; issued before anything waits
@@ -200,6 +209,16 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			cinfo[tid] = order | (maxpo_c << 8) | (minpo_c << 12) | (narrow_c << 16);
 		}
 
+		if(take_fps) {
+			// rows of the fixed candidates (the leading ones) from the table: entry (k, p) belongs to the candidate of order k, if
+			// there is one; every thread of the workgroup takes part, whatever the block length
+			for(uint32_t ci = 0; ci < gn && FA_CAND_KIND(chdr[ci]) == 0; ci++) {
+				const uint32_t order = FA_CAND_ORDER(chdr[ci]);
+				if((tid >> 6) == order) psum[(size_t)ci * SF_ROW + (tid & 63u)] = (SUM)(fps_a >> wasted);
+				if(order == 4u && tid < 64u) psum[(size_t)ci * SF_ROW + tid] = (SUM)(fps_b >> wasted);
+			}
+		}
+
 		// ---- |residual| sums per finest partition.  Samples before `order` carry no residual: each
 		// sample of the chunk goes (statically) to one of three accumulators, of which thread 0 keeps
 		// only the tail, thread 1 the tail and the head, every other thread all three.
@@ -231,7 +250,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			// residual: those go to separate sums that the frame's first thread drops.
 			uint32_t nfixed = 0;
 			while(nfixed < gn && FA_CAND_KIND(chdr[nfixed]) == 0) nfixed++;
-			if(nfixed) {
+			if(nfixed && !take_fps) {
 				SUM fT[5], fH[5];
 #pragma unroll
 				for(int k = 0; k < 5; k++) { fT[k] = 0; fH[k] = 0; }
