@@ -30,6 +30,8 @@ size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out);
 void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
 void fa_launch_pack_general(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, int large);
 void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st);
+void fa_launch_offsets(const FaCfg *c, const FaWork *w, hipStream_t st);
+int fa_pack_direct_ok(const void *pcm, const FaCfg *c);
 }
 
 static thread_local char g_last_error[256] = "";
@@ -280,6 +282,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
 		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_fshift = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
 		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u),
+		o_lb = take(F * 8u),
 		o_fps = take((p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? G * 320u * 4u : 0u);   // only the 16-bit stereo kernels use it
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
@@ -290,6 +293,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
 	w.xs_spill = (int32_t*)(b + o_spill);
+	w.lb = (unsigned long long*)(b + o_lb); w.out = 0; w.out_cap = 0; w.frame_bytes_out = 0;
 	w.fixed_psum = (p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? (uint32_t*)(b + o_fps) : (uint32_t*)0;
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.frame_shift = (uint32_t*)(b + o_fshift); w.window = (const float*)(b + o_window);
 
@@ -442,9 +446,15 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 	if(tm) hipEventRecord(e->ev[3], st);
 	fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
 	if(tm) hipEventRecord(e->ev[4], st);
-	if(!(c.debug & 3u)) fa_launch_pack(d_pcm, &c, &e->work, st);
+	// frames straight into the caller's buffer where the register-resident pack kernel takes the batch; else into slots and a copy
+	c.direct_out = (fa_pack_direct_ok(d_pcm, &c) && !(c.debug & 3u)) ? 1u : 0u;
+	FaWork ww = e->work;
+	ww.out = (uint8_t*)d_out; ww.out_cap = out_cap; ww.frame_bytes_out = d_frame_bytes;
+	if(c.direct_out) HIP_TRY(hipMemsetAsync(ww.lb, 0, (size_t)c.F * 8u, st));
+	if(!(c.debug & 3u)) fa_launch_pack(d_pcm, &c, &ww, st);
 	if(tm) hipEventRecord(e->ev[5], st);
-	fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
+	if(c.direct_out) fa_launch_offsets(&c, &ww, st);
+	else fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
 	if(tm) hipEventRecord(e->ev[6], st);
 	HIP_TRY(hipGetLastError());
 	return FLACAMD_OK;

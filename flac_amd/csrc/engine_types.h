@@ -46,6 +46,7 @@ struct FaCfg {
 	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
 	uint32_t G;               // F * nsig
 	uint32_t debug;           // development ablation switches (FLACAMD_DEBUG), 0 in production
+	uint32_t direct_out;      // the register-resident pack kernel writes every frame at its final place in the caller's buffer (FaWork::out), found by a look-back over the frame sizes: no copy out of per-frame slots
 	uint32_t fixed_psum;      // the 16-bit stereo preparation kernel leaves the fixed predictors' |residual| sums per finest partition (FaWork::fixed_psum) and the register-resident search kernel takes them from there
 };
 
@@ -127,6 +128,11 @@ struct FaWork {
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial
 	unsigned long long *dbg;      // [FA_DBG_WORDS] development timestamps (FLACAMD_DEBUG & 0x1000), unused in production
+	// FaCfg::direct_out (set per call)
+	unsigned long long *lb;       // [F] look-back state of every frame, zeroed before the pack kernel: bits 63..62 = 0 nothing yet, 1 the frame's own size, 2 the size of all frames up to and including it; the rest the value
+	uint8_t  *out;                // the caller's output buffer
+	unsigned long long out_cap;   // its size
+	uint32_t *frame_bytes_out;    // the caller's array of frame sizes (may be null)
 };
 
 #ifdef __HIPCC__

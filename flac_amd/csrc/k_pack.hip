@@ -455,12 +455,16 @@ __global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ p
 // whole frame is assembled in LDS and flushed once: coalesced word stores, CRC-16 per thread
 // segment folded with x^(32 w) multipliers.  Four barriers per frame.
 #define PF_THREADS 256
+#define PF_LB_OWN (1ull << 62)
+#define PF_LB_ALL (2ull << 62)
+#define PF_LB_MASK (3ull << 62)
 #define PF_CH 16
 #define PF_W (HIST + PF_CH)
 
 struct PackFastShared {
 	uint32_t wave_tot[PF_THREADS / 64][2];
 	uint32_t crc_acc;
+	unsigned long long out_off;   // where the frame goes in the caller's buffer (FaCfg::direct_out)
 	uint16_t crc4[4][256];
 };
 
@@ -699,9 +703,16 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 #pragma unroll
 	for(int sc = 0; sc < NSUB; sc++) { start[sc] = total_bits; total_bits += d[sc].head_bits + tot[sc]; }
 	if(total_bits > cap_bits || __syncthreads_or(bad ? 1 : 0)) { // cannot happen for estimates that did not wrap; never write past the buffer
-		if(tid == 0) { atomicOr(w.status, 1u); w.frame_bytes[f] = 0; }
+		if(tid == 0) {
+			atomicOr(w.status, 1u); w.frame_bytes[f] = 0;
+			if(c.direct_out) __hip_atomic_store(&w.lb[f], PF_LB_OWN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the frames behind this one must not wait for it
+		}
 		return;
 	}
+	// The frame's size is known before a bit of it is written: tell the frames behind (see the look-back below)
+	const uint32_t frame_nb = ((total_bits + 7u) >> 3) + 2u;
+	if(c.direct_out && tid == 0)
+		__hip_atomic_store(&w.lb[f], (f == 0u ? PF_LB_ALL : PF_LB_OWN) | (unsigned long long)frame_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 	// ---- frame header (one lane of the last wave), subframe heads (token-parallel, first wave)
 	if(tid == PF_THREADS - 1u) {
@@ -779,9 +790,38 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	}
 	__syncthreads();
 
-	// ---- flush: whole words to the slot, CRC-16 of thread segments combined with x^(32 w)
+	// ---- where the frame goes (FaCfg::direct_out).  Frames lie end to end in the caller's buffer, so frame f starts at the
+	// sum of the sizes of the frames before it.  Every workgroup has published its own size (state "own"); the first wave
+	// walks back over its predecessors 64 at a time, adding sizes, until it meets one that already knows the total up to and
+	// including itself (state "all"), then publishes its own total.  Workgroups are handed out in index order, so a
+	// predecessor that has not published yet is running (or done) and will: the wait is short and cannot deadlock.
 	const uint32_t full = total_bits >> 5;
-	if(!(c.debug & 0x100u)) for(uint32_t i = tid; i < full; i += PF_THREADS) slot_words[i] = __builtin_bswap32(bitbuf[i]);
+	if(c.direct_out && tid < 64u) {
+		unsigned long long before = 0;
+		if(f > 0u) {
+			int32_t hi = (int32_t)f - 1;
+			for(;;) {
+				const int32_t j = hi - (int32_t)tid;
+				const unsigned long long stt = j >= 0 ? __hip_atomic_load(&w.lb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PF_LB_ALL;   // before frame 0: nothing, known
+				const uint32_t flag = (uint32_t)(stt >> 62);
+				const unsigned long long knows_all = __ballot(flag == 2u), silent = __ballot(flag == 0u);
+				const uint32_t stop = knows_all ? (uint32_t)__builtin_ctzll(knows_all) : 64u;   // nearest predecessor that knows its total
+				const unsigned long long upto = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
+				if(silent & upto) { __builtin_amdgcn_s_sleep(2); continue; }
+				unsigned long long v = tid <= stop ? (stt & ~PF_LB_MASK) : 0ull;
+#pragma unroll
+				for(int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+				before += v;
+				if(knows_all) break;
+				hi -= 64;
+			}
+			if(tid == 0) __hip_atomic_store(&w.lb[f], PF_LB_ALL | (before + frame_nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if(tid == 0) sh.out_off = before + (c.multi == 2u ? w.frame_shift[f] : 0u);
+	}
+
+	// ---- whole words to the slot (unless the frame goes straight to the caller), CRC-16 of thread segments combined with x^(32 w)
+	if(!c.direct_out && !(c.debug & 0x100u)) for(uint32_t i = tid; i < full; i += PF_THREADS) slot_words[i] = __builtin_bswap32(bitbuf[i]);
 	if(!(c.debug & 0x20u)) {
 		const uint32_t segw = (full + PF_THREADS - 1u) / PF_THREADS;
 		const uint32_t e1 = (segw * tid < full) ? full - segw * tid : 0u, b0 = (e1 > segw) ? e1 - segw : 0u;
@@ -794,18 +834,48 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	__syncthreads();
 
 	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905)
+	const uint32_t tail_bits = total_bits & 31u, tail_bytes = (tail_bits + 7u) >> 3;
+	const uint32_t body_bytes = full * 4u + tail_bytes;
 	if(tid == 0) {
-		const uint32_t tail_bits = total_bits & 31u, tail_bytes = (tail_bits + 7u) >> 3;
-		const uint32_t body_bytes = full * 4u + tail_bytes;
 		uint32_t crc = sh.crc_acc;
 		const uint32_t last = bitbuf[full];
 		for(uint32_t i = 0; i < tail_bytes; i++) {
 			const uint32_t byte = (last >> (24u - 8u * i)) & 0xffu;
-			slot[full * 4u + i] = (uint8_t)byte;
+			if(!c.direct_out) slot[full * 4u + i] = (uint8_t)byte;
 			crc = ((crc << 8) & 0xffffu) ^ sh.crc4[0][(crc >> 8) ^ byte];
 		}
-		slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc;
+		if(!c.direct_out) { slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc; }
+		else {
+			// the footer joins the image (byte b of the frame is bits 31 - 8 (b & 3) .. of word b >> 2; the pad bits are zero already)
+			const uint32_t b0 = body_bytes, b1 = body_bytes + 1u;
+			bitbuf[b0 >> 2] |= (crc >> 8) << (24u - 8u * (b0 & 3u));
+			bitbuf[b1 >> 2] |= (crc & 0xffu) << (24u - 8u * (b1 & 3u));
+		}
 		w.frame_bytes[f] = body_bytes + 2u;
+		if(c.direct_out && w.frame_bytes_out) w.frame_bytes_out[f] = body_bytes + 2u;
+	}
+	if(!c.direct_out) return;
+	__syncthreads();
+
+	// ---- the image to its place: bytes up to the first aligned word of the destination, aligned words put together from
+	// the image's big-endian words, the bytes that are left
+	{
+		const uint32_t nb = body_bytes + 2u;
+		const unsigned long long off = sh.out_off;
+		if(off + nb > w.out_cap) { if(tid == 0) atomicOr(w.status, 2u); return; }
+		uint8_t *dst = w.out + off;
+		const uint32_t lead = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u), head = lead < nb ? lead : nb;
+		auto image_byte = [&](uint32_t bb) { return (uint8_t)(bitbuf[bb >> 2] >> (24u - 8u * (bb & 3u))); };
+		if(tid < head) dst[tid] = image_byte(tid);
+		const uint32_t nwords = (nb - head) >> 2;
+		uint32_t *dw = (uint32_t*)(dst + head);
+		const uint32_t sh8 = head * 8u;   // the image is word-aligned, so every destination word starts `head` bytes into an image word
+		for(uint32_t i = tid; i < nwords; i += PF_THREADS) {
+			const uint32_t w0 = __builtin_bswap32(bitbuf[i]), w1 = __builtin_bswap32(bitbuf[i + 1u]);
+			dw[i] = sh8 ? (w0 >> sh8) | (w1 << (32u - sh8)) : w0;
+		}
+		const uint32_t done = head + nwords * 4u;
+		if(tid < nb - done) dst[done + tid] = image_byte(done + tid);
 	}
 }
 
@@ -938,6 +1008,15 @@ extern "C" void fa_launch_pack_general(const void *pcm, const FaCfg *c, const Fa
 		hipLaunchKernelGGL(fa_pack_kernel<false>, dim3(c->F), dim3(256), lds, st, pcm, *c, *w, words);
 	}
 }
+
+// the frame sizes' exclusive scan alone (frames already in place: FaCfg::direct_out)
+extern "C" void fa_launch_offsets(const FaCfg *c, const FaWork *w, hipStream_t st)
+{
+	hipLaunchKernelGGL(fa_scan_kernel, dim3((c->F + 1023u) / 1024u), dim3(1024), 0, st, *c, *w);
+}
+
+// can the pack stage put the frames of this batch straight into the caller's buffer?
+extern "C" int fa_pack_direct_ok(const void *pcm, const FaCfg *c) { return fa_pack_fast_ok(pcm, c) && !(c->debug & 0x80000u); }
 
 extern "C" void fa_launch_gather(const FaCfg *c, const FaWork *w, void *out, size_t out_cap, uint32_t *frame_bytes_out, hipStream_t st)
 {
