@@ -798,8 +798,10 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	const uint32_t full = total_bits >> 5;
 	if(c.direct_out && tid < 64u) {
 		unsigned long long before = 0;
+		bool gave_up = false;
 		if(f > 0u) {
 			int32_t hi = (int32_t)f - 1;
+			uint32_t waits = 0;
 			for(;;) {
 				const int32_t j = hi - (int32_t)tid;
 				const unsigned long long stt = j >= 0 ? __hip_atomic_load(&w.lb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PF_LB_ALL;   // before frame 0: nothing, known
@@ -807,7 +809,13 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 				const unsigned long long knows_all = __ballot(flag == 2u), silent = __ballot(flag == 0u);
 				const uint32_t stop = knows_all ? (uint32_t)__builtin_ctzll(knows_all) : 64u;   // nearest predecessor that knows its total
 				const unsigned long long upto = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
-				if(silent & upto) { __builtin_amdgcn_s_sleep(2); continue; }
+				if(silent & upto) {
+					// a bound on the wait, so that this wave ends whatever happens to the others: the batch then counts as one with
+					// a frame that did not fit, and goes through the slot-and-copy path once more
+					if(++waits > (1u << 22)) { gave_up = true; break; }
+					__builtin_amdgcn_s_sleep(2);
+					continue;
+				}
 				unsigned long long v = tid <= stop ? (stt & ~PF_LB_MASK) : 0ull;
 #pragma unroll
 				for(int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
@@ -815,9 +823,10 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 				if(knows_all) break;
 				hi -= 64;
 			}
-			if(tid == 0) __hip_atomic_store(&w.lb[f], PF_LB_ALL | (before + frame_nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if(tid == 0 && !gave_up) __hip_atomic_store(&w.lb[f], PF_LB_ALL | (before + frame_nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if(tid == 0 && gave_up) atomicOr(w.status, 1u);
 		}
-		if(tid == 0) sh.out_off = before + (c.multi == 2u ? w.frame_shift[f] : 0u);
+		if(tid == 0) sh.out_off = gave_up ? ~0ull : before + (c.multi == 2u ? w.frame_shift[f] : 0u);
 	}
 
 	// ---- whole words to the slot (unless the frame goes straight to the caller), CRC-16 of thread segments combined with x^(32 w)
@@ -833,41 +842,35 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	}
 	__syncthreads();
 
-	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905)
+	// ---- zero-pad to a byte, CRC-16, footer (stream_encoder.c:2890-2905): the bytes after the last whole word, by one lane;
+	// with FaCfg::direct_out the whole words go to their place meanwhile
 	const uint32_t tail_bits = total_bits & 31u, tail_bytes = (tail_bits + 7u) >> 3;
-	const uint32_t body_bytes = full * 4u + tail_bytes;
+	const uint32_t body_bytes = full * 4u + tail_bytes, nb = body_bytes + 2u;
+	const unsigned long long off = c.direct_out ? sh.out_off : 0ull;
+	const bool place = c.direct_out && off != ~0ull && off + nb <= w.out_cap;
+	if(c.direct_out && off != ~0ull && !place && tid == 0) atomicOr(w.status, 2u);
+	uint8_t *dst = place ? w.out + off : slot;
 	if(tid == 0) {
 		uint32_t crc = sh.crc_acc;
 		const uint32_t last = bitbuf[full];
+		const bool store = place || !c.direct_out;
 		for(uint32_t i = 0; i < tail_bytes; i++) {
 			const uint32_t byte = (last >> (24u - 8u * i)) & 0xffu;
-			if(!c.direct_out) slot[full * 4u + i] = (uint8_t)byte;
+			if(store) dst[full * 4u + i] = (uint8_t)byte;
 			crc = ((crc << 8) & 0xffffu) ^ sh.crc4[0][(crc >> 8) ^ byte];
 		}
-		if(!c.direct_out) { slot[body_bytes] = (uint8_t)(crc >> 8); slot[body_bytes + 1u] = (uint8_t)crc; }
-		else {
-			// the footer joins the image (byte b of the frame is bits 31 - 8 (b & 3) .. of word b >> 2; the pad bits are zero already)
-			const uint32_t b0 = body_bytes, b1 = body_bytes + 1u;
-			bitbuf[b0 >> 2] |= (crc >> 8) << (24u - 8u * (b0 & 3u));
-			bitbuf[b1 >> 2] |= (crc & 0xffu) << (24u - 8u * (b1 & 3u));
-		}
-		w.frame_bytes[f] = body_bytes + 2u;
-		if(c.direct_out && w.frame_bytes_out) w.frame_bytes_out[f] = body_bytes + 2u;
+		if(store) { dst[body_bytes] = (uint8_t)(crc >> 8); dst[body_bytes + 1u] = (uint8_t)crc; }
+		w.frame_bytes[f] = nb;
+		if(c.direct_out && w.frame_bytes_out) w.frame_bytes_out[f] = nb;
 	}
-	if(!c.direct_out) return;
-	__syncthreads();
-
-	// ---- the image to its place: bytes up to the first aligned word of the destination, aligned words put together from
-	// the image's big-endian words, the bytes that are left
-	{
-		const uint32_t nb = body_bytes + 2u;
-		const unsigned long long off = sh.out_off;
-		if(off + nb > w.out_cap) { if(tid == 0) atomicOr(w.status, 2u); return; }
-		uint8_t *dst = w.out + off;
-		const uint32_t lead = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u), head = lead < nb ? lead : nb;
+	if(place) {
+		// bytes up to the first aligned word of the destination, aligned words put together from the image's big-endian
+		// words, the bytes that are left of the whole words
+		const uint32_t wb = full * 4u;
+		const uint32_t lead = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u), head = lead < wb ? lead : wb;
 		auto image_byte = [&](uint32_t bb) { return (uint8_t)(bitbuf[bb >> 2] >> (24u - 8u * (bb & 3u))); };
 		if(tid < head) dst[tid] = image_byte(tid);
-		const uint32_t nwords = (nb - head) >> 2;
+		const uint32_t nwords = (wb - head) >> 2;
 		uint32_t *dw = (uint32_t*)(dst + head);
 		const uint32_t sh8 = head * 8u;   // the image is word-aligned, so every destination word starts `head` bytes into an image word
 		for(uint32_t i = tid; i < nwords; i += PF_THREADS) {
@@ -875,7 +878,7 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 			dw[i] = sh8 ? (w0 >> sh8) | (w1 << (32u - sh8)) : w0;
 		}
 		const uint32_t done = head + nwords * 4u;
-		if(tid < nb - done) dst[done + tid] = image_byte(done + tid);
+		if(tid < wb - done) dst[done + tid] = image_byte(done + tid);
 	}
 }
 
