@@ -26,6 +26,8 @@ void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream
 void fa_launch_model(const FaCfg *c, const FaWork *w, hipStream_t st);
 size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg);
 void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st);
+void fa_launch_search2(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st, hipStream_t st_rest);
+uint32_t fa_search_rest_frames(const void *pcm, const FaCfg *c);
 size_t fa_pack_lds_bytes(const FaCfg *c, uint32_t *bitbuf_words_out);
 void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
 void fa_launch_pack_general(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, int large);
@@ -444,7 +446,15 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 	if(tm) (void)hipEventRecord(e->ev[2], st);
 	fa_launch_model(&c, &e->work, st);
 	if(tm) hipEventRecord(e->ev[3], st);
-	fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
+	if(fa_search_rest_frames(d_pcm, &c) && !(c.debug & 0x10000u)) {
+		// the short last frame's search beside the others' (it is a handful of workgroups with the chip to themselves otherwise)
+		HIP_TRY(hipEventRecord(e->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+		fa_launch_search2(d_pcm, &c, &e->work, e->cand_group, e->sum64, st, e->side);
+		HIP_TRY(hipEventRecord(e->ev_join, e->side));
+		HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+	}
+	else fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
 	if(tm) hipEventRecord(e->ev[4], st);
 	// frames straight into the caller's buffer where the register-resident pack kernel takes the batch; else into slots and a copy
 	c.direct_out = (fa_pack_direct_ok(d_pcm, &c) && !(c.debug & 3u)) ? 1u : 0u;

@@ -330,7 +330,18 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 extern "C" int fa_search_fast_ok(const void *pcm, const FaCfg *c);
 extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, uint32_t frames, hipStream_t st);
 
-extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st)
+// st_rest: where the general kernel goes.  In a single-stream batch it takes only what the register-resident kernel leaves
+// (a short last frame): a workgroup or four that would otherwise sit alone on the chip for their whole run, so the caller
+// may give them a stream of their own beside the other kernel (and joins it before the pack stage).
+extern "C" void fa_launch_search2(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st, hipStream_t st_rest);
+extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st) { fa_launch_search2(pcm, c, w, cg, sum64, st, st); }
+// frames the general kernel has to take although the register-resident one runs (0: none, or it runs alone)
+extern "C" uint32_t fa_search_rest_frames(const void *pcm, const FaCfg *c)
+{
+	if(!fa_search_fast_ok(pcm, c) || c->multi) return 0u;
+	return c->last_n == c->N ? 0u : (c->F > 1u ? 1u : 0u);
+}
+extern "C" void fa_launch_search2(const void *pcm, const FaCfg *c, const FaWork *w, uint32_t cg, int sum64, hipStream_t st, hipStream_t st_rest)
 {
 	// full-length frames of common streams go to the register-resident kernel; a short last
 	// frame and everything else to the general one
@@ -346,7 +357,7 @@ extern "C" void fa_launch_search(const void *pcm, const FaCfg *c, const FaWork *
 	const size_t lds = fa_search_lds_bytes(c, cg);
 	auto launch = [&](auto kernel) {
 		(void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(kernel, dim3(rest), dim3(256), lds, st, pcm, *c, *w, cg, g0);
+		hipLaunchKernelGGL(kernel, dim3(rest), dim3(256), lds, fast_frames ? st_rest : st, pcm, *c, *w, cg, g0);
 	};
 	if(c->spill) { if(sum64) launch(fa_search_kernel<unsigned long long, true>); else launch(fa_search_kernel<uint32_t, true>); }
 	else { if(sum64) launch(fa_search_kernel<unsigned long long, false>); else launch(fa_search_kernel<uint32_t, false>); }

@@ -15,8 +15,12 @@ for r in csv.DictReader(open(f)):
     if not k.startswith("fd_"): continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVES": n[k] += 1
+import json
+out = {"command": "bench.py --no-cpu-baseline --no-configs --no-api --steps 1 --warmup 1 (decode leg: one hour of 16/44.1 stereo)", "note": "averages per wave; the decode kernel's two waves per workgroup (parser, restorer) are averaged together; SQ_WAVE_CYCLES and the SQ_WAIT counters are in quad-cycles", "kernels": {}}
 for k, v in acc.items():
     launches = n[k]
     w = v["SQ_WAVES"] / launches
     print(k, "launches", launches, "waves/launch %.0f" % w, " per wave:", " ".join("%s=%.0f" % (c.replace("SQ_", ""), v[c] / launches / w) for c in sorted(v) if c != "SQ_WAVES"))
+    out["kernels"][k] = {"launches": launches, "waves_per_launch": int(round(w)), "per_wave": {c: round(v[c] / launches / w, 1) for c in sorted(v) if c != "SQ_WAVES"}}
+json.dump(out, open("$ROOT/gpurun_out/decode_pmc_summary.json", "w"), indent=1, sort_keys=True)
 EOF

@@ -9,6 +9,9 @@ timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OU
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/t_kernel_stats.csv", recursive=True)[0]
+rows = list(csv.reader(open(f)))
+keep = [rows[0]] + [r for r in rows[1:] if r[0].replace("void ", "").startswith("fd_")]
+csv.writer(open("$ROOT/gpurun_out/decode_kernel_stats.csv", "w", newline="")).writerows(keep)
 for r in csv.DictReader(open(f)):
     if r["Name"].replace("void ", "").startswith("fd_"):
         print("%-40s calls %4s avg %10.1f us" % (r["Name"].split("(")[0][:40], r["Calls"], float(r["AverageNs"]) / 1e3))
