@@ -231,3 +231,51 @@ def test_stress_signals_on_the_register_resident_path(gpu_engine, kind, level, b
         assert frames16 == o["frames"], "int16 input"
     finally:
         enc.close()
+
+
+@pytest.mark.parametrize("flag", [0x80000, 0x40000, 0xC0000])
+def test_alternative_stage_arrangements_give_the_same_frames(gpu_engine, monkeypatch, flag):
+    """The register-resident kernels take two shortcuts that other configurations cannot: the pack kernel writes frames
+    at their final place (look-back over the frame sizes) instead of into slots for the gather kernel, and the search
+    kernel takes the fixed predictors' partition sums from the preparation pass instead of computing them.  The
+    development switches that turn each of them off must not change a byte."""
+    from flac_amd import synth
+    pcm = synth.music_like(3.0, seed=91).astype(np.int16)
+    for level in (8, 5, 2):
+        fp, _ = ob.make_params(2, 16, 44100, level=level)
+        want = ob.oracle_encode(fp, pcm.astype(np.int32))["frames"]
+        e, (frames, _) = _encode(gpu_engine, 2, 16, 44100, dict(level=level), pcm)
+        e.close()
+        monkeypatch.setenv("FLACAMD_DEBUG", hex(flag))
+        try:
+            e, (alt, _) = _encode(gpu_engine, 2, 16, 44100, dict(level=level), pcm)
+            e.close()
+        finally:
+            monkeypatch.delenv("FLACAMD_DEBUG")
+        assert frames == want and alt == want
+
+
+@pytest.mark.parametrize("channels", [2, 3])
+def test_output_buffer_too_small_is_reported(gpu_engine, channels):
+    """Frames that do not fit the caller's buffer are not written past its end: the call reports the capacity error
+    (stereo: the pack kernel's in-place path; three channels: the slot-and-copy path)."""
+    import torch
+    from flac_amd import synth
+    pcm = np.ascontiguousarray(np.stack([synth.music_like(1.0, seed=5 + k)[:, 0] for k in range(channels)], axis=1).astype(np.int32))
+    p = gpu_engine.make_params(channels, 16, 44100, level=5)
+    enc = gpu_engine.Encoder(p, max_frames=16)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    guard = 4096
+    d_out = torch.full((1000 + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    d_fb = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(gpu_engine.EngineError) as ei:
+        enc.encode_device(d_pcm.data_ptr(), gpu_engine.PCM_S32, len(pcm), d_out.data_ptr(), 1000, d_fb.data_ptr())
+    assert ei.value.code == -6
+    assert bool((d_out[1000:] == 0xA5).all())
+    # and with room the same encoder carries on
+    d_big = torch.empty(pcm.nbytes + 4096, dtype=torch.uint8, device="cuda")
+    total = enc.encode_device(d_pcm.data_ptr(), gpu_engine.PCM_S32, len(pcm), d_big.data_ptr(), d_big.numel(), d_fb.data_ptr())
+    fp, _ = ob.make_params(channels, 16, 44100, level=5)
+    want = b"".join(ob.oracle_encode(fp, pcm)["frames"])
+    assert bytes(d_big[:total].cpu().numpy()) == want
+    enc.close()
