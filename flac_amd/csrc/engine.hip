@@ -897,7 +897,12 @@ extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint3
 		for(int i = 0; i < PIPE_PARKED; i++) {
 			flacamd_pipe *q = g_parked[i];
 			if(q && q->nlanes == ndevices && q->key_batch == batch_frames && q->key_depth == depth && 0 == memcmp(&q->key_params, params, sizeof *params)
-				&& 0 == memcmp(q->key_devices, devices, sizeof(int) * ndevices)) { g_parked[i] = 0; *out = q; return FLACAMD_OK; }
+				&& 0 == memcmp(q->key_devices, devices, sizeof(int) * ndevices)) {
+				// idle (nothing in flight), and as good as new for its next owner: batch 0 goes to slot 0 again, which is what
+				// flacamd_pipe_slot_buffer promises and what a caller that reads its own input back (the MD5 thread) relies on
+				q->head = q->tail = 0;
+				g_parked[i] = 0; *out = q; return FLACAMD_OK;
+			}
 		}
 	}
 	flacamd_pipe *pp = (flacamd_pipe*)calloc(1, sizeof *pp);

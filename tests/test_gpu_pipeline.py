@@ -101,3 +101,21 @@ def test_stream_object_md5_thread_and_slot_reuse(gpu_engine):
     assert e.streaminfo["md5sum"] == hashlib.md5(pcm.astype("<i2").tobytes()).digest()
     assert bytes(e.buf)[-sum(map(len, want["frames"])):] == b"".join(want["frames"])
     e.close()
+
+
+def test_encoder_after_encoder_starts_from_a_clean_pipe(gpu_engine):
+    """An encoder object whose settings equal its predecessor's takes over that one's idle pipe (pinned buffers are
+    dear to make).  Whatever number of batches the predecessor left behind, the newcomer's first batch must sit where
+    its MD5 thread looks for it: the digest in STREAMINFO is the digest of the samples handed over."""
+    import hashlib
+    pcm = synth.music_like(6.0, seed=8).astype(np.int32)
+    for nbatches_before in (1, 2, 4, 5):
+        a = stream.MemoryEncoder(seekable=True)
+        assert a.set_compression_level(5) and a.set_batch_frames(4) and a.init() == stream.INIT_OK
+        assert a.process_interleaved(pcm[:4096 * 4 * (nbatches_before - 1) + 100]) and a.finish()
+        a.close()
+        b = stream.MemoryEncoder(seekable=True)
+        assert b.set_compression_level(5) and b.set_batch_frames(4) and b.init() == stream.INIT_OK
+        assert b.process_interleaved(pcm) and b.finish()
+        assert b.streaminfo["md5sum"] == hashlib.md5(pcm.astype("<i2").tobytes()).digest(), nbatches_before
+        b.close()

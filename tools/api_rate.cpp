@@ -15,22 +15,55 @@ extern "C" {
 #include <vector>
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-struct Sink { uint64_t bytes, frames; };
+struct Sink { uint64_t bytes, frames; std::vector<uint8_t> *keep; uint64_t pos; };
 static FLAC__StreamEncoderWriteStatus on_write(const FLAC__StreamEncoder *, const FLAC__byte buf[], size_t bytes, unsigned samples, unsigned, void *cd)
 {
-	Sink *s = (Sink*)cd; s->bytes += bytes; if(samples) s->frames++; (void)buf;
+	Sink *s = (Sink*)cd; s->bytes += bytes; if(samples) s->frames++;
+	if(s->keep) { if(s->keep->size() < s->pos + bytes) s->keep->resize(s->pos + bytes); memcpy(s->keep->data() + s->pos, buf, bytes); s->pos += bytes; }
 	return FLAC__STREAM_ENCODER_WRITE_STATUS_OK;
 }
+static FLAC__StreamEncoderSeekStatus on_seek(const FLAC__StreamEncoder *, FLAC__uint64 off, void *cd) { ((Sink*)cd)->pos = off; return FLAC__STREAM_ENCODER_SEEK_STATUS_OK; }
+static FLAC__StreamEncoderTellStatus on_tell(const FLAC__StreamEncoder *, FLAC__uint64 *off, void *cd) { *off = ((Sink*)cd)->pos; return FLAC__STREAM_ENCODER_TELL_STATUS_OK; }
 
-static double run_stream(const int32_t *pcm, uint64_t n, unsigned level, unsigned batch, int md5, unsigned chunk, const int *dev, unsigned ndev, uint64_t *bytes_out)
+// the decoder object fed from memory, frames handed to a callback that looks at one sample of each
+struct Source { const uint8_t *p; size_t n, at; uint64_t samples; int32_t sum; };
+static FLAC__StreamDecoderReadStatus on_read(const FLAC__StreamDecoder *, FLAC__byte buf[], size_t *bytes, void *cd)
 {
-	Sink sink = { 0, 0 };
+	Source *s = (Source*)cd; size_t k = s->n - s->at < *bytes ? s->n - s->at : *bytes;
+	if(k == 0) { *bytes = 0; return FLAC__STREAM_DECODER_READ_STATUS_END_OF_STREAM; }
+	memcpy(buf, s->p + s->at, k); s->at += k; *bytes = k;
+	return FLAC__STREAM_DECODER_READ_STATUS_CONTINUE;
+}
+static FLAC__StreamDecoderWriteStatus on_frame(const FLAC__StreamDecoder *, const FLAC__Frame *fr, const FLAC__int32 *const buf[], void *cd)
+{
+	Source *s = (Source*)cd; s->samples += fr->header.blocksize; s->sum += buf[0][0] + buf[1][fr->header.blocksize - 1];
+	return FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE;
+}
+static void on_error(const FLAC__StreamDecoder *, FLAC__StreamDecoderErrorStatus st, void *) { fprintf(stderr, "decoder error %d\n", (int)st); }
+static double run_decode(const std::vector<uint8_t> &stream, int md5, uint64_t expect)
+{
+	Source src = { stream.data(), stream.size(), 0, 0, 0 };
+	FLAC__StreamDecoder *d = FLAC__stream_decoder_new();
+	FLAC__stream_decoder_set_md5_checking(d, md5);
+	if(FLAC__stream_decoder_init_stream(d, on_read, 0, 0, 0, 0, on_frame, 0, on_error, &src) != FLAC__STREAM_DECODER_INIT_STATUS_OK) { fprintf(stderr, "decoder init failed\n"); exit(2); }
+	const double t0 = now();
+	if(!FLAC__stream_decoder_process_until_end_of_stream(d)) { fprintf(stderr, "decode failed\n"); exit(2); }
+	const FLAC__bool ok = FLAC__stream_decoder_finish(d);
+	const double dt = now() - t0;
+	FLAC__stream_decoder_delete(d);
+	if(src.samples != expect || (md5 && !ok)) { fprintf(stderr, "decode: %llu samples (expected %llu), md5 verdict %d\n", (unsigned long long)src.samples, (unsigned long long)expect, (int)ok); exit(2); }
+	return dt;
+}
+
+static double run_stream(const int32_t *pcm, uint64_t n, unsigned level, unsigned batch, int md5, unsigned chunk, const int *dev, unsigned ndev, uint64_t *bytes_out, std::vector<uint8_t> *keep = 0)
+{
+	Sink sink = { 0, 0, keep, 0 };
 	FLAC__StreamEncoder *e = FLAC__stream_encoder_new();
 	FLAC__stream_encoder_set_compression_level(e, level);
 	FLAC__stream_encoder_set_do_md5(e, md5);
 	flacamd_stream_encoder_set_batch_frames(e, batch);
 	flacamd_stream_encoder_set_devices(e, ndev, dev);
-	if(FLAC__stream_encoder_init_stream(e, on_write, 0, 0, 0, &sink) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) { fprintf(stderr, "init failed\n"); exit(2); }
+	if(FLAC__stream_encoder_init_stream(e, on_write, keep ? on_seek : 0, keep ? on_tell : 0, 0, &sink) != FLAC__STREAM_ENCODER_INIT_STATUS_OK) { fprintf(stderr, "init failed\n"); exit(2); }
 	const double t0 = now();
 	for(uint64_t i = 0; i < n; i += chunk) {
 		const unsigned k = (unsigned)(n - i < chunk ? n - i : chunk);
@@ -85,6 +118,15 @@ int main(int argc, char **argv)
 	for(int rep = 0; rep < 3; rep++) { const double dt = run_stream(pcm32.data(), n, level, batch, 0, 1u << 20, dev, ndev, &bytes); if(dt < best_off) best_off = dt; }
 	for(int rep = 0; rep < 2; rep++) { const double dt = run_stream(pcm32.data(), n, level, batch, 1, 1u << 20, dev, ndev, 0); if(dt < best_on) best_on = dt; }
 	for(int rep = 0; rep < 2; rep++) { const double dt = run_stream(pcm32.data(), n, level, batch, 0, 4096, dev, ndev, 0); if(dt < best_small) best_small = dt; }
+	// the same stream (with its MD5 in place) back through the decoder object
+	double dec_off = 1e30, dec_on = 1e30;
+	{
+		std::vector<uint8_t> stream;
+		run_stream(pcm32.data(), n, level, batch, 1, 1u << 20, dev, ndev, 0, &stream);
+		run_decode(stream, 0, n);
+		for(int rep = 0; rep < 3; rep++) { const double dt = run_decode(stream, 0, n); if(dt < dec_off) dec_off = dt; }
+		for(int rep = 0; rep < 2; rep++) { const double dt = run_decode(stream, 1, n); if(dt < dec_on) dec_on = dt; }
+	}
 	// the engine-level pipe on the same buffer
 	double pipe32 = 0;
 	{
@@ -105,7 +147,8 @@ int main(int argc, char **argv)
 		flacamd_pipe_destroy(pp);
 		if(total + 86 + 0 < bytes - 200 || total > bytes) fprintf(stderr, "warning: pipe bytes %llu vs stream bytes %llu\n", (unsigned long long)total, (unsigned long long)bytes);
 	}
-	printf("{\"stream_md5_off\": %.1f, \"stream_md5_on\": %.1f, \"stream_md5_off_4096_sample_calls\": %.1f, \"encode_host\": %.1f, \"md5_alone\": %.1f, "
+	printf("{\"decoder_md5_off\": %.1f, \"decoder_md5_on\": %.1f, ", n / dec_off / 1e6, n / dec_on / 1e6);
+	printf("\"stream_md5_off\": %.1f, \"stream_md5_on\": %.1f, \"stream_md5_off_4096_sample_calls\": %.1f, \"encode_host\": %.1f, \"md5_alone\": %.1f, "
 		"\"pcie_h2d_GBs\": %.2f, \"pcie_d2h_GBs\": %.2f, \"h2d_bound_int32_stereo\": %.1f, \"unit\": \"MSamples/s\", \"wide_samples\": %llu, \"level\": %u, \"batch_frames\": %u, "
 		"\"devices\": %u, \"stream_bytes\": %llu, \"note\": \"PCM handed over as int32 in pageable host memory in 1 Mi-sample calls (and 4096-sample calls), frames delivered to a C write callback; best of 3\"}\n",
 		n / best_off / 1e6, n / best_on / 1e6, n / best_small / 1e6, pipe32, md5_alone, h2d, d2h, h2d * 1e9 / 8.0 / 1e6, (unsigned long long)n, level, batch, ndev, (unsigned long long)bytes);
