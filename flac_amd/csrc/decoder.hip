@@ -1007,6 +1007,7 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 				a = (int32_t)((uint32_t)mid + (uint32_t)side) >> 1; b = (int32_t)((uint32_t)mid - (uint32_t)side) >> 1;
 			}
 			if(c.pcm_format == FLACAMD_PCM_S16) ((uint32_t*)pcm)[s0 + i] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+			else if(c.pcm_format == FLACAMD_PCM_S32_FRAMES) { int32_t *o = (int32_t*)pcm + s0 * 2u; o[i] = a; o[n + i] = b; }
 			else ((int2*)pcm)[s0 + i] = make_int2(a, b);
 		}
 	}
@@ -1016,6 +1017,7 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 			const uint32_t i = t / c.channels, ch = t - i * c.channels;
 			const int32_t v = src[(size_t)ch * c.ws_stride + i];
 			if(c.pcm_format == FLACAMD_PCM_S16) ((int16_t*)pcm)[(s0 + i) * c.channels + ch] = (int16_t)v;
+			else if(c.pcm_format == FLACAMD_PCM_S32_FRAMES) ((int32_t*)pcm)[s0 * c.channels + (size_t)ch * n + i] = v;
 			else ((int32_t*)pcm)[(s0 + i) * c.channels + ch] = v;
 		}
 	}
@@ -1101,7 +1103,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	void *d_pcm, int pcm_format, uint64_t pcm_cap_samples, uint64_t h_info[4], void *stream)
 {
 	if(!d || !d_bytes || !d_pcm || nbytes == 0 || nbytes > d->max_bytes) return FLACAMD_E_INVALID_ARGUMENT;
-	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16 && pcm_format != FLACAMD_PCM_S32_FRAMES) return FLACAMD_E_INVALID_ARGUMENT;
 	if(pcm_format == FLACAMD_PCM_S16 && d->cfg.bps > 16) return FLACAMD_E_INVALID_ARGUMENT;
 	if(((uintptr_t)d_bytes & 15u) != 0) return FLACAMD_E_INVALID_ARGUMENT;   // the bit reader fetches 16-byte chunks
 	hipStream_t st = (hipStream_t)stream;

@@ -825,6 +825,14 @@ struct PipeSlot {
 	int collected;
 };
 
+extern "C" void *flacamd_host_alloc(size_t bytes)
+{
+	void *p = 0;
+	if(bytes == 0 || pinned_alloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return p;
+}
+extern "C" void flacamd_host_free(void *p, size_t bytes) { if(p) pinned_free(p, bytes); }
+
 struct PipeLane { int device; flacamd_encoder *enc; hipStream_t hs, cs, ds; };
 
 struct flacamd_pipe {

@@ -76,6 +76,27 @@ static void md5_feed_pcm(md5_state *m, const int32_t *interleaved, size_t nvalue
 	if(fill) md5_update(m, scratch, fill);
 }
 
+/* the same for one frame held channel by channel (chan[c][i]): the samples go into the checksum interleaved (md5.c:394-420) */
+static void md5_feed_planar(md5_state *m, const int32_t *const chan[], unsigned channels, size_t nsamples, unsigned bits_per_sample, uint8_t *scratch, size_t scratch_bytes)
+{
+	const unsigned nb = (bits_per_sample + 7) / 8; size_t i, fill = 0; unsigned b, c;
+	if(channels == 2 && nb == 2) { /* the common case, two bytes of each channel in turn */
+		const int32_t *l = chan[0], *r = chan[1];
+		for(i = 0; i < nsamples; i++) {
+			const uint32_t v = ((uint32_t)l[i] & 0xffffu) | ((uint32_t)r[i] << 16);
+			scratch[fill] = (uint8_t)v; scratch[fill + 1] = (uint8_t)(v >> 8); scratch[fill + 2] = (uint8_t)(v >> 16); scratch[fill + 3] = (uint8_t)(v >> 24);
+			fill += 4;
+			if(fill + 4 > scratch_bytes) { md5_update(m, scratch, fill); fill = 0; }
+		}
+	}
+	else for(i = 0; i < nsamples; i++) for(c = 0; c < channels; c++) {
+		const uint32_t v = (uint32_t)chan[c][i];
+		for(b = 0; b < nb; b++) scratch[fill++] = (uint8_t)(v >> (8 * b));
+		if(fill + 4 > scratch_bytes) { md5_update(m, scratch, fill); fill = 0; }
+	}
+	if(fill) md5_update(m, scratch, fill);
+}
+
 /* the same for samples held as int16 (streams of at most 16 bits): two-byte samples are already the byte stream */
 static void md5_feed_pcm16(md5_state *m, const int16_t *interleaved, size_t nvalues, unsigned bits_per_sample, uint8_t *scratch, size_t scratch_bytes)
 {

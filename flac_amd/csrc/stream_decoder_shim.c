@@ -62,7 +62,7 @@ struct FLAC__StreamDecoder {
 	 * those parameters takes the frame, and the event carries its samples */
 	flacamd_decoder *alt_eng; unsigned alt_ch, alt_bps, alt_bs; size_t alt_bytes;
 	struct alt_frame { int32_t *pcm; flacamd_subframe_info sub[8]; unsigned ch, bps; } **f_alt;
-	size_t planar_cap;
+	size_t planar_cap, pcm_bytes;
 	int search_warned;               /* LOST_SYNC already reported for the sync search in progress (frame_sync_'s `first`) */
 	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
 	int32_t *planar; uint8_t *md5_scratch;
@@ -95,7 +95,7 @@ FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
 static void dec_free(FLAC__StreamDecoder *d)
 {
 	if(d->eng) { flacamd_decoder_destroy(d->eng); d->eng = 0; }
-	free(d->in); d->in = 0; free(d->pcm); d->pcm = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
+	flacamd_host_free(d->in, d->in_cap); d->in = 0; flacamd_host_free(d->pcm, d->pcm_bytes); d->pcm = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
 	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
 	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
 	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
@@ -219,7 +219,7 @@ static FLAC__StreamDecoderInitStatus dec_init(FLAC__StreamDecoder *d, FLAC__Stre
 	if(!rcb || !wcb || !errcb || (scb && (!tcb || !lcb || !ecb))) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
 	if(flacamd_device_count() <= d->device) return FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR; /* no device to decode on: there is no CPU path */
 	d->read_cb = rcb; d->seek_cb = scb; d->tell_cb = tcb; d->length_cb = lcb; d->eof_cb = ecb; d->write_cb = wcb; d->metadata_cb = mcb; d->error_cb = errcb; d->client_data = client_data;
-	d->in_cap = (size_t)1 << 20; d->in = (uint8_t*)malloc(d->in_cap);
+	d->in_cap = (size_t)1 << 20; d->in = (uint8_t*)flacamd_host_alloc(d->in_cap);   /* page-locked: the window goes to the device at bus speed */
 	d->md5_scratch = (uint8_t*)malloc(65536);
 	if(!d->in || !d->md5_scratch) { dec_free(d); return FLAC__STREAM_DECODER_INIT_STATUS_MEMORY_ALLOCATION_ERROR; }
 	d->in_len = d->in_pos = 0; d->in_base = 0; d->eof = 0; d->warned_sync = 0;
@@ -281,8 +281,10 @@ static FLAC__bool fill_range(FLAC__StreamDecoder *d, size_t least, size_t need)
 		d->in_base += d->in_pos; d->in_len -= d->in_pos; d->in_pos = 0;
 	}
 	if(need > d->in_cap) {
-		uint8_t *nb = (uint8_t*)realloc(d->in, need);
+		uint8_t *nb = (uint8_t*)flacamd_host_alloc(need);
 		if(!nb) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		memcpy(nb, d->in, d->in_len);
+		flacamd_host_free(d->in, d->in_cap);
 		d->in = nb; d->in_cap = need;
 	}
 	while(d->in_len < least && !d->eof) {
@@ -366,7 +368,8 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 		d->f_alt = (struct alt_frame**)calloc(d->ev_cap, sizeof(struct alt_frame*));
 		d->planar_cap = (size_t)si->max_blocksize * si->channels;
 		if(!d->sub || !d->f_cand || !d->frame_cand || !d->f_alt) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
-		d->pcm = (int32_t*)malloc(sizeof(int32_t) * d->pcm_cap * si->channels);
+		d->pcm_bytes = sizeof(int32_t) * d->pcm_cap * si->channels;
+		d->pcm = (int32_t*)flacamd_host_alloc(d->pcm_bytes);   /* page-locked: a batch's samples come back at bus speed */
 		d->f_off = (uint64_t*)malloc(8u * d->ev_cap); d->f_num = (uint64_t*)malloc(8u * d->ev_cap); d->f_end = (uint64_t*)malloc(8u * d->ev_cap); d->f_sn = (uint64_t*)malloc(8u * d->ev_cap);
 		d->f_bs = (uint32_t*)malloc(4u * d->ev_cap); d->f_asg = (uint32_t*)malloc(4u * d->ev_cap); d->f_kind = (uint8_t*)malloc(d->ev_cap);
 		d->c_pos = (uint64_t*)malloc(8u * d->eng_frames); d->c_end = (uint64_t*)malloc(8u * d->eng_frames); d->c_num = (uint64_t*)malloc(8u * d->eng_frames); d->c_off = (uint64_t*)malloc(8u * d->eng_frames);
@@ -692,7 +695,7 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		if(avail(d) == 0) { d->state = FLAC__STREAM_DECODER_END_OF_STREAM; return 1; }
 		window = avail(d) < d->batch_bytes ? avail(d) : d->batch_bytes;
 		for(;;) {
-			rc = flacamd_decode_host(d->eng, d->in + d->in_pos, window, d->pcm, FLACAMD_PCM_S32, d->pcm_cap, info);
+			rc = flacamd_decode_host(d->eng, d->in + d->in_pos, window, d->pcm, FLACAMD_PCM_S32_FRAMES, d->pcm_cap, info);   /* every frame as the write callback wants it */
 			if(rc == FLACAMD_E_CAPACITY && window > 1024u) { window /= 2; continue; } /* more frames in the window than a batch holds */
 			break;
 		}
@@ -825,7 +828,8 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	}
 	d->last = frame.header;
 	if(d->do_md5 && deliver) {
-		if(src) md5_feed_pcm(&d->md5, src, (size_t)n * ch, bps, d->md5_scratch, 65536);
+		if(src && alt) md5_feed_pcm(&d->md5, src, (size_t)n * ch, bps, d->md5_scratch, 65536);
+		else if(src) { for(c = 0; c < ch; c++) bufs[c] = src + (size_t)c * n; md5_feed_planar(&d->md5, bufs, ch, n, bps, d->md5_scratch, 65536); }
 		else { /* a zeroed frame goes through the checksum like any other (:2964) */
 			memset(d->planar, 0, sizeof(int32_t) * (size_t)n * ch);
 			md5_feed_pcm(&d->md5, d->planar, (size_t)n * ch, bps, d->md5_scratch, 65536);
@@ -842,6 +846,7 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	if(!deliver) { if(alt) { free(alt->pcm); free(alt); } return 1; }
 	for(c = 0; c < ch; c++) {
 		int32_t *dst = d->planar + (size_t)c * n;
+		if(src && !alt) { bufs[c] = src + (size_t)c * n + skip; continue; }   /* the batch came back frame by frame, channel by channel: handed on as it lies */
 		if(src) for(i = skip; i < n; i++) dst[i - skip] = src[i * ch + c];
 		else memset(dst, 0, sizeof(int32_t) * n);
 		bufs[c] = dst;

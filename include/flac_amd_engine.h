@@ -55,8 +55,17 @@ enum {
  * channel, one "wide sample" = one sample of every channel). */
 enum {
 	FLACAMD_PCM_S32 = 0,  /* int32 per sample, right-justified: what process_interleaved takes (stream_encoder.h:1760) */
-	FLACAMD_PCM_S16 = 1   /* int16 per sample (streams with bits_per_sample <= 16) */
+	FLACAMD_PCM_S16 = 1,  /* int16 per sample (streams with bits_per_sample <= 16) */
+	FLACAMD_PCM_S32_FRAMES = 2  /* decoder output only: int32 per sample, frame after frame, each frame as channel 0's blocksize samples,
+	                             * then channel 1's, ...: the buffers a FLAC__StreamDecoderWriteCallback is handed
+	                             * (stream_decoder.h:509-511, output[channel][sample] of stream_decoder.c:2963) with no host-side copy */
 };
+
+/* Page-locked host memory for the buffers of the *_host entry points: copies to and from it run at the speed of the
+ * bus (pageable memory goes through a staging copy at a fraction of it).  Freed buffers are kept for the next caller
+ * (flacamd_pipe_trim gives them back).  No counterpart in the reference: its data never leaves the host. */
+void *flacamd_host_alloc(size_t bytes);
+void flacamd_host_free(void *p, size_t bytes);
 
 /* The analysis settings of one stream: the fields of FLAC__StreamEncoderProtected that the
  * frame path reads (include/protected/stream_encoder.h:78-108). Zero means "default" for
