@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FLACAMD_LIB") or os.path.join(_HERE, "libflacamd.so")   # the override is a development aid for comparing builds
 
-PCM_S32, PCM_S16 = 0, 1
+PCM_S32, PCM_S16, PCM_S32_FRAMES = 0, 1, 2
 
 WINDOWS = ["bartlett", "bartlett_hann", "blackman", "blackman_harris_4term_92db", "connes", "flattop", "gauss",
            "hamming", "hann", "kaiser_bessel", "nuttall", "rectangle", "triangle", "tukey", "welch"]
@@ -338,6 +338,15 @@ class Decoder:
         info = (C.c_uint64 * 4)()
         _check(self._lib.flacamd_decode_host(self._h, buf.ctypes.data, len(buf), pcm.ctypes.data, fmt, cap_samples, info), "flacamd_decode_host")
         return pcm[:int(info[1])], dict(frames=int(info[0]), samples=int(info[1]), first_number=int(info[2]), bytes=int(info[3]))
+
+    def decode_host_frames(self, data, cap_samples):
+        """The same with FLACAMD_PCM_S32_FRAMES: returns (flat int32 array, info dict); a frame of n samples that starts at
+        wide sample s lies at [s * channels, (s + n) * channels) as channel 0's n samples, then channel 1's, ..."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        pcm = np.zeros(cap_samples * self.channels, dtype=np.int32)
+        info = (C.c_uint64 * 4)()
+        _check(self._lib.flacamd_decode_host(self._h, buf.ctypes.data, len(buf), pcm.ctypes.data, PCM_S32_FRAMES, cap_samples, info), "flacamd_decode_host")
+        return pcm[:int(info[1]) * self.channels], dict(frames=int(info[0]), samples=int(info[1]), first_number=int(info[2]), bytes=int(info[3]))
 
     def set_tolerant(self, on=True):
         """Accept byte ranges whose CRC-valid frames do not tile them (flacamd_decoder_set_tolerant)."""

@@ -173,3 +173,23 @@ def test_byte_range_shares_stitch_to_the_stream(gpu_engine, world, kind):
     assert np.array_equal(sharding.stitch_decoded(parts, len(data)), pcm)
     if world == 8 and kind == "music-8":
         assert any(p["frames"] == 0 for p in parts) or all(p["frames"] > 0 for p in parts)   # ranges without a frame start are legal
+
+
+@pytest.mark.parametrize("name", ["st16-level8", "8ch24-8-e-p", "st16-8-bs17", "mono16-8", "fsd3", "len4097"])
+def test_frames_layout_is_the_write_callbacks(gpu_engine, name):
+    """FLACAMD_PCM_S32_FRAMES: every frame as channel 0's samples, then channel 1's, ... (what a decoder write callback
+    is handed, stream_decoder.h:509-511), frame after frame; the same samples as the interleaved layout."""
+    g = load_golden(name)
+    m = g["meta"]
+    blob = b"".join(g["frames"])
+    sizes = ob.oracle_encode(ob.make_params(m["channels"], m["bps"], m["rate"], **{k: (v if k != "apodization" else [tuple(a) for a in v]) for k, v in m["params"].items()})[0], g["pcm"])["samples"]
+    dec = gpu_engine.Decoder(m["channels"], m["bps"], max(max(sizes), 16), max_frames=len(g["frames"]) + 64, max_bytes=len(blob) + 64)
+    flat, info = dec.decode_host_frames(blob, len(g["pcm"]) + 16)
+    dec.close()
+    assert info["frames"] == len(g["frames"]) and info["samples"] == len(g["pcm"])
+    ch, at = m["channels"], 0
+    for n in sizes:
+        frame = flat[at * ch:(at + n) * ch].reshape(ch, n)
+        assert np.array_equal(frame.T, g["pcm"][at:at + n]), (name, at)
+        at += n
+    assert at == len(g["pcm"])
