@@ -624,14 +624,24 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 			if(s.po && (dps % PF_CH)) bad = true;
 			const uint32_t p = s.po ? i0 / dps : 0u;
 			if(s.type >= FA_SUB_FIXED) kk[sc] = kpre[sc];
+			// which signal is the same for the whole workgroup: one branch around the loop, not a chain of selects per sample
 			int32_t xw[PF_W];
+			const uint32_t which = c.midside ? s.sig : (uint32_t)sc;
+			if(which == 0u) {
 #pragma unroll
-			for(int j = 0; j < PF_W; j++) {
-				const int32_t l = xa[j], r = xb[j];
-				int32_t v;
-				if(c.midside) v = s.sig == 0 ? l : s.sig == 1 ? r : s.sig == 2 ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
-				else v = sc == 0 ? l : r;
-				xw[j] = v >> s.wasted;
+				for(int j = 0; j < PF_W; j++) xw[j] = xa[j] >> s.wasted;
+			}
+			else if(which == 1u) {
+#pragma unroll
+				for(int j = 0; j < PF_W; j++) xw[j] = xb[j] >> s.wasted;
+			}
+			else if(which == 2u) {
+#pragma unroll
+				for(int j = 0; j < PF_W; j++) xw[j] = ((int32_t)((uint32_t)xa[j] + (uint32_t)xb[j]) >> 1) >> s.wasted;
+			}
+			else {
+#pragma unroll
+				for(int j = 0; j < PF_W; j++) xw[j] = (int32_t)((uint32_t)xa[j] - (uint32_t)xb[j]) >> s.wasted;
 			}
 			const uint32_t smask = s.sbps < 32u ? (1u << s.sbps) - 1u : 0xffffffffu;
 			if(s.type == FA_SUB_VERBATIM) {

@@ -165,13 +165,23 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				if(active && rel >= 0) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
 				raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
 			}
-			// signal = (ca * left + cb * right) >> (cs + wasted): L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058)
-			const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
-			const uint32_t shv = wasted + (s == 2u ? 1u : 0u);
+			// L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), less the wasted bits.  Which one is the same for the whole
+			// workgroup: one branch around the loop instead of arithmetic that covers all four per sample
+			if(s == 0u) {
 #pragma unroll
-			for(int j = 0; j < SF_W; j++) {
-				const int32_t l = (int32_t)(int16_t)(raw[j] & 0xffffu), r = (int32_t)raw[j] >> 16;
-				xw[j] = (ca * l + cb * r) >> shv;
+				for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> wasted;
+			}
+			else if(s == 1u) {
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)raw[j] >> (16u + wasted);
+			}
+			else if(s == 2u) {
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + wasted);
+			}
+			else {
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> wasted;
 			}
 		}
 		else {
@@ -184,12 +194,21 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				if(active && rel >= 0) v = *(const uint4*)((const int32_t*)pcm + (base + (uint32_t)rel) * 2u);
 				l[2*j] = (int32_t)v.x; r[2*j] = (int32_t)v.y; l[2*j+1] = (int32_t)v.z; r[2*j+1] = (int32_t)v.w;
 			}
+			if(s == 0u) {
 #pragma unroll
-			for(int j = 0; j < SF_W; j++) {
-				int32_t v;
-				if(c.midside) v = s == 0u ? l[j] : s == 1u ? r[j] : s == 2u ? ((int32_t)((uint32_t)l[j] + (uint32_t)r[j]) >> 1) : (int32_t)((uint32_t)l[j] - (uint32_t)r[j]);
-				else v = s == 0u ? l[j] : r[j];
-				xw[j] = v >> wasted;
+				for(int j = 0; j < SF_W; j++) xw[j] = l[j] >> wasted;
+			}
+			else if(s == 1u) {
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = r[j] >> wasted;
+			}
+			else if(s == 2u) {   // (mid and side only exist with c.midside)
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)((uint32_t)l[j] + (uint32_t)r[j]) >> 1) >> wasted;
+			}
+			else {
+#pragma unroll
+				for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)((uint32_t)l[j] - (uint32_t)r[j]) >> wasted;
 			}
 		}
 
