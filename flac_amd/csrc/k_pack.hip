@@ -545,7 +545,8 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 
 // 256 threads x 16 samples capped at 128 registers: four workgroups per CU, 0.96 ms per hour of audio (512 x 8 at two /
 // three workgroups per CU: 1.30 / 1.03 ms; tighter caps spill more than the extra workgroups hide).
-template<int NSUB>
+// PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), kept as one register per wide sample
+template<int NSUB, bool PACKED16>
 __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -589,9 +590,27 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 	}
 	const FrameHdrFields hf = fa_frame_header_fields(c, n, fa_frame_num(c, w, f));
 
-	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels
-	int32_t xa[PF_W], xb[PF_W];
-	{
+	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels.  16-bit stereo stays packed (left | right << 16,
+	// one register per wide sample) until a subframe's signal is formed from it: half the registers, and nothing spills
+	constexpr bool packed16 = PACKED16;
+	int32_t xa[PACKED16 ? 1 : PF_W], xb[PACKED16 ? 1 : PF_W];
+	uint32_t raw[PACKED16 ? PF_W : 1];
+	if constexpr(PACKED16) {
+#pragma unroll
+		for(int j = 0; j < PF_W / 4; j++) {
+			const int32_t rel = (int32_t)i0 - HIST + 4 * j;
+			uint4 v = make_uint4(0u, 0u, 0u, 0u);
+			if(rel >= 0 && (uint32_t)rel + 4u <= n) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
+			else if(rel >= 0 && (uint32_t)rel < n) { // the tail of a short last block: never read past the end of the stream
+				const uint32_t *q = (const uint32_t*)pcm + base + (uint32_t)rel;
+				v.x = q[0];
+				if((uint32_t)rel + 1u < n) v.y = q[1];
+				if((uint32_t)rel + 2u < n) v.z = q[2];
+			}
+			raw[4 * j] = v.x; raw[4 * j + 1] = v.y; raw[4 * j + 2] = v.z; raw[4 * j + 3] = v.w;
+		}
+	}
+	else {
 		const uint64_t end = base + n;
 #pragma unroll
 		for(int j = 0; j < PF_W / 4; j++) {
@@ -627,6 +646,25 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 			// which signal is the same for the whole workgroup: one branch around the loop, not a chain of selects per sample
 			int32_t xw[PF_W];
 			const uint32_t which = c.midside ? s.sig : (uint32_t)sc;
+			if constexpr(PACKED16) {
+				if(which == 0u) {
+#pragma unroll
+					for(int j = 0; j < PF_W; j++) xw[j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> s.wasted;
+				}
+				else if(which == 1u) {
+#pragma unroll
+					for(int j = 0; j < PF_W; j++) xw[j] = (int32_t)raw[j] >> (16u + s.wasted);
+				}
+				else if(which == 2u) {
+#pragma unroll
+					for(int j = 0; j < PF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + s.wasted);
+				}
+				else {
+#pragma unroll
+					for(int j = 0; j < PF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> s.wasted;
+				}
+			}
+			else {
 			if(which == 0u) {
 #pragma unroll
 				for(int j = 0; j < PF_W; j++) xw[j] = xa[j] >> s.wasted;
@@ -642,6 +680,7 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 			else {
 #pragma unroll
 				for(int j = 0; j < PF_W; j++) xw[j] = (int32_t)((uint32_t)xa[j] - (uint32_t)xb[j]) >> s.wasted;
+			}
 			}
 			const uint32_t smask = s.sbps < 32u ? (1u << s.sbps) - 1u : 0xffffffffu;
 			if(s.type == FA_SUB_VERBATIM) {
@@ -883,8 +922,12 @@ __global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void 
 		const uint32_t nwords = (wb - head) >> 2;
 		uint32_t *dw = (uint32_t*)(dst + head);
 		const uint32_t sh8 = head * 8u;   // the image is word-aligned, so every destination word starts `head` bytes into an image word
-		for(uint32_t i = tid; i < nwords; i += PF_THREADS) {
-			const uint32_t w0 = __builtin_bswap32(bitbuf[i]), w1 = __builtin_bswap32(bitbuf[i + 1u]);
+		// a wave's 64 words start on a 256-byte boundary of the destination (the first wave's round begins short), so that
+		// every store fills whole cache lines and only a frame's first and last line are shared with its neighbours
+		const int32_t skew = (int32_t)(((uintptr_t)dw & 255u) >> 2);
+		for(int32_t i = (int32_t)tid - skew; i < (int32_t)nwords; i += PF_THREADS) {
+			if(i < 0) continue;
+			const uint32_t w0 = __builtin_bswap32(bitbuf[i]), w1 = __builtin_bswap32(bitbuf[i + 1]);
 			dw[i] = sh8 ? (w0 >> sh8) | (w1 << (32u - sh8)) : w0;
 		}
 		const uint32_t done = head + nwords * 4u;
@@ -986,13 +1029,17 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 		const size_t lds = ((size_t)words * 4u + 15u) & ~(size_t)15u;
 		if(c->channels == 2) hipLaunchKernelGGL(fa_assign_kernel<2>, dim3(c->F), dim3(64), 0, st, *c, *w);
 		else hipLaunchKernelGGL(fa_assign_kernel<1>, dim3(c->F), dim3(64), 0, st, *c, *w);
-		if(c->channels == 2) {
-			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL(fa_pack_fast_kernel<2>, dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
+		if(c->channels == 2 && c->pcm_format == FLACAMD_PCM_S16) {
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((fa_pack_fast_kernel<2, true>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
+		}
+		else if(c->channels == 2) {
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((fa_pack_fast_kernel<2, false>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
 		}
 		else {
-			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL(fa_pack_fast_kernel<1>, dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((fa_pack_fast_kernel<1, false>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
 		}
 		return;
 	}
