@@ -74,6 +74,53 @@ __device__ __forceinline__ void md5_super_block(uint32_t (&h)[4], const void *pc
 	}
 }
 
+// 16 bytes from an address that is only as aligned as its samples (the hardware takes such loads; the type says so)
+struct __attribute__((packed, aligned(2))) Md5Raw16 { uint32_t w[4]; };
+__device__ __forceinline__ uint4 md5_load16(const uint8_t *p) { const Md5Raw16 v = *(const Md5Raw16*)p; return make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]); }
+
+// The bulk of a stream, 64 values at a time, for two-byte samples held as int16 (the memory IS the byte stream: 128 bytes,
+// two blocks) and three-byte samples held as int32 (256 bytes of memory, 192 of stream, three blocks).  A lane fetches its
+// bytes 16 at a time - every lane reads a stream of its own, so a load instruction touches 64 cache lines whatever its
+// width - and the next 64 values are on their way while the blocks of these are worked through: the chain of a block's
+// 64 steps is all a lane has to do, and nothing else would hide the latency of its loads.
+template<int RAWVEC>
+struct Md5Chunk { uint4 v[RAWVEC]; };
+template<int RAWVEC>
+__device__ __forceinline__ Md5Chunk<RAWVEC> md5_fetch(const uint8_t *p)
+{
+	Md5Chunk<RAWVEC> c;
+#pragma unroll
+	for(int j = 0; j < RAWVEC; j++) c.v[j] = md5_load16(p + 16 * j);
+	return c;
+}
+__device__ __forceinline__ void md5_two_blocks(uint32_t (&h)[4], const Md5Chunk<8> &c)
+{
+#pragma unroll
+	for(int blk = 0; blk < 2; blk++) {
+		uint32_t m[16];
+#pragma unroll
+		for(int i = 0; i < 4; i++) { const uint4 q = c.v[blk * 4 + i]; m[4 * i] = q.x; m[4 * i + 1] = q.y; m[4 * i + 2] = q.z; m[4 * i + 3] = q.w; }
+		md5_block(h, m);
+	}
+}
+__device__ __forceinline__ void md5_three_blocks(uint32_t (&h)[4], const Md5Chunk<16> &c)
+{
+	uint32_t mm[48];
+#pragma unroll
+	for(int j = 0; j < 16; j++) { // four 3-byte samples -> three words
+		const uint4 q = c.v[j];
+		const uint32_t a = q.x & 0xffffffu, b = q.y & 0xffffffu, cc = q.z & 0xffffffu, d = q.w & 0xffffffu;
+		mm[3 * j] = a | (b << 24); mm[3 * j + 1] = (b >> 8) | (cc << 16); mm[3 * j + 2] = (cc >> 16) | (d << 8);
+	}
+#pragma unroll
+	for(int blk = 0; blk < 3; blk++) {
+		uint32_t m[16];
+#pragma unroll
+		for(int i = 0; i < 16; i++) m[i] = mm[blk * 16 + i];
+		md5_block(h, m);
+	}
+}
+
 __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
 	const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends, uint32_t nstreams, uint8_t *__restrict__ digests)
 {
@@ -86,6 +133,28 @@ __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm
 	uint64_t t = s0 * channels;
 	const uint64_t tend = s1 * channels;
 	uint64_t total = 0;
+	if(nb == 2u && fmt == FLACAMD_PCM_S16 && t + 64u <= tend) {
+		const uint8_t *p = (const uint8_t*)pcm + t * 2u;
+		Md5Chunk<8> nxt = md5_fetch<8>(p);
+		for(; t + 64u <= tend; t += 64u) {
+			const Md5Chunk<8> cur = nxt;
+			p += 128;
+			if(t + 128u <= tend) nxt = md5_fetch<8>(p);
+			md5_two_blocks(h, cur);
+			total += 128u;
+		}
+	}
+	else if(nb == 3u && fmt == FLACAMD_PCM_S32 && t + 64u <= tend) {
+		const uint8_t *p = (const uint8_t*)pcm + t * 4u;
+		Md5Chunk<16> nxt = md5_fetch<16>(p);
+		for(; t + 64u <= tend; t += 64u) {
+			const Md5Chunk<16> cur = nxt;
+			p += 256;
+			if(t + 128u <= tend) nxt = md5_fetch<16>(p);
+			md5_three_blocks(h, cur);
+			total += 192u;
+		}
+	}
 	for(; t + 64u <= tend; t += 64u) {
 		if(nb == 1u) md5_super_block<1>(h, pcm, fmt, t);
 		else if(nb == 2u) md5_super_block<2>(h, pcm, fmt, t);
