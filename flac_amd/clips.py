@@ -47,10 +47,22 @@ def encode_groups_device(plans, device):
     from concurrent.futures import ThreadPoolExecutor
     torch.cuda.synchronize(device)
     streams = [torch.cuda.Stream(device=device) for _ in plans]
+    ready = None
+    digests = [None] * len(plans)
+    if len(plans) > 1:
+        # the digests of all groups in one pass beside the coding stages: as long as the longest clip, once
+        md5_stream = torch.cuda.Stream(device=device)
+        digests = [torch.empty(len(p[3]) * 16, dtype=torch.uint8, device=p[1].device) for p in plans]
+        engine.md5_groups_device(device, [(p[1].data_ptr(), p[2], p[0].channels, int(p[0].params.bits_per_sample), p[3], p[4], d.data_ptr())
+                                          for p, d in zip(plans, digests)], stream=md5_stream.cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record(md5_stream)
 
     def one(k):
         torch.cuda.set_device(device)
         enc, d_pcm, fmt, starts, lens, F = plans[k]
+        if ready is not None:
+            enc.use_digests(digests[k].data_ptr(), ready.cuda_event)
         return encode_group_device(enc, d_pcm, fmt, starts, lens, F, stream=streams[k].cuda_stream)
 
     if len(plans) == 1:

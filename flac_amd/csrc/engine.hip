@@ -205,6 +205,7 @@ struct flacamd_encoder {
 	// per-call tables of the multi-stream entry points: pinned host staging and a device buffer, both grow-only
 	void *h_tab; size_t h_tab_bytes; void *d_tab; size_t d_tab_bytes;
 	hipStream_t md5s; hipEvent_t ev_tab, ev_md5;   // the clip batch hashes on a stream of its own beside the coding stages
+	const uint8_t *given_digests; void *given_ready;   // flacamd_encoder_use_digests: for the next clip batch only
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -604,6 +605,13 @@ __global__ void __launch_bounds__(64) fa_clip_heads_kernel(FaCfg c, FaWork w, co
 	for(uint32_t i = lane; i < FLACAMD_STREAM_HEAD_BYTES; i += 64u) out[off + i] = h[i];
 }
 
+extern "C" int flacamd_encoder_use_digests(flacamd_encoder *e, const uint8_t *d_digests, void *ready_event)
+{
+	if(!e) return FLACAMD_E_INVALID_ARGUMENT;
+	e->given_digests = d_digests; e->given_ready = d_digests ? ready_event : 0;
+	return FLACAMD_OK;
+}
+
 extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nclips,
 	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint64_t *h_stream_off, uint64_t *h_total_bytes, void *stream)
 {
@@ -651,10 +659,15 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 	HIP_TRY(hipMemcpyAsync(e->work.frame_shift, fshift, F * 4u, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(db, hb + o_clip, clip_bytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipEventRecord(e->ev_tab, st));
-	// the digests: one lane per clip, a serial chain as long as the clip (md5.c:394-420); beside the coding stages
-	HIP_TRY(hipStreamWaitEvent(e->md5s, e->ev_tab, 0));
-	fa_launch_md5(d_pcm, (uint32_t)pcm_format, e->cfg.channels, e->cfg.bps, d_cs, d_ce, nclips, d_dig, e->md5s);
-	HIP_TRY(hipEventRecord(e->ev_md5, e->md5s));
+	// the digests: one lane per clip, a serial chain as long as the clip (md5.c:394-420); beside the coding stages -
+	// unless the caller had them made already (flacamd_md5_groups_device hashes the clips of many batches in one pass)
+	const uint8_t *use_dig = e->given_digests; void *use_ready = e->given_ready;
+	e->given_digests = 0; e->given_ready = 0;
+	if(!use_dig) {
+		HIP_TRY(hipStreamWaitEvent(e->md5s, e->ev_tab, 0));
+		fa_launch_md5(d_pcm, (uint32_t)pcm_format, e->cfg.channels, e->cfg.bps, d_cs, d_ce, nclips, d_dig, e->md5s);
+		HIP_TRY(hipEventRecord(e->ev_md5, e->md5s));
+	}
 
 	FaCfg c = e->cfg;
 	c.pcm_format = (uint32_t)pcm_format;
@@ -665,10 +678,11 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 	rc = run_batch(e, c, d_pcm, d_out, out_cap, 0, &total, st);
 	const uint64_t need = total + (uint64_t)FLACAMD_STREAM_HEAD_BYTES * nclips;
 	if(h_total_bytes) *h_total_bytes = need;
-	if(rc != FLACAMD_OK) { (void)hipStreamSynchronize(e->md5s); return rc; }
-	HIP_TRY(hipStreamWaitEvent(st, e->ev_md5, 0));
+	if(rc != FLACAMD_OK) { if(!use_dig) (void)hipStreamSynchronize(e->md5s); return rc; }
+	if(!use_dig) HIP_TRY(hipStreamWaitEvent(st, e->ev_md5, 0));
+	else if(use_ready) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)use_ready, 0));
 	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
-	hipLaunchKernelGGL(fa_clip_heads_kernel, dim3(nclips), dim3(64), 0, st, c, e->work, d_cs, d_ce, d_cf, d_cn, nclips, (const uint8_t*)d_dig, (uint8_t*)d_out, (unsigned long long)out_cap, d_so);
+	hipLaunchKernelGGL(fa_clip_heads_kernel, dim3(nclips), dim3(64), 0, st, c, e->work, d_cs, d_ce, d_cf, d_cn, nclips, use_dig ? use_dig : (const uint8_t*)d_dig, (uint8_t*)d_out, (unsigned long long)out_cap, d_so);
 	HIP_TRY(hipGetLastError());
 	uint32_t status = 0;
 	HIP_TRY(hipMemcpyAsync(hb + o_back, d_so, (n + 1u) * 8u, hipMemcpyDeviceToHost, st));

@@ -9,6 +9,7 @@
 #include "engine_types.h"
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <string.h>
 
 __constant__ uint32_t md5_k[64] = {
 	0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,
@@ -121,12 +122,31 @@ __device__ __forceinline__ void md5_three_blocks(uint32_t (&h)[4], const Md5Chun
 	}
 }
 
+// one stream: [s0, s1) of pcm in wide samples -> 16 bytes at digest
+__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest);
+
 __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
 	const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends, uint32_t nstreams, uint8_t *__restrict__ digests)
 {
 	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
 	if(sidx >= nstreams) return;
-	const uint64_t s0 = starts[sidx], s1 = ends[sidx];
+	md5_one_stream(pcm, fmt, channels, bps, starts[sidx], ends[sidx], digests + (size_t)sidx * 16u);
+}
+
+// the same for streams of several buffers and formats: what a lane hashes comes from its own record (a group's lanes
+// are next to one another, so a wave is nearly always of one format)
+struct FaMd5Rec { const void *pcm; uint8_t *digest; uint64_t s0, s1; uint32_t fmt, channels, bps, pad; };
+__global__ void __launch_bounds__(64) fa_md5_multi_kernel(const FaMd5Rec *__restrict__ recs, uint32_t nstreams)
+{
+	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
+	if(sidx >= nstreams) return;
+	const FaMd5Rec r = recs[sidx];
+	if(!r.pcm) return;   // filler up to a whole wave
+	md5_one_stream(r.pcm, r.fmt, r.channels, r.bps, r.s0, r.s1, r.digest);
+}
+
+__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest)
+{
 	const uint32_t nb = (bps + 7u) / 8u;
 	uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
 	// bulk: 64 values at a time are a whole number of blocks
@@ -187,7 +207,7 @@ __global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm
 	push(0x80u);
 	while(fill != 56u) push(0u);
 	for(uint32_t k = 0; k < 8; k++) push((uint32_t)(bits >> (8u * k)) & 0xffu);
-	for(uint32_t i = 0; i < 16; i++) digests[(size_t)sidx * 16u + i] = (uint8_t)(h[i >> 2] >> (8u * (i & 3u)));
+	for(uint32_t i = 0; i < 16; i++) digest[i] = (uint8_t)(h[i >> 2] >> (8u * (i & 3u)));
 }
 
 extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
@@ -269,4 +289,55 @@ extern "C" void fa_launch_md5(const void *d_pcm, uint32_t pcm_format, uint32_t c
 	uint32_t nstreams, uint8_t *d_digests, hipStream_t st)
 {
 	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, pcm_format, channels, bits_per_sample, d_starts, d_ends, nstreams, d_digests);
+}
+
+// ---- the digests of several clip batches in one launch
+namespace {
+std::mutex g_md5_groups_lock;
+struct Md5GroupsBuf { void *h; void *d; size_t cap; };
+Md5GroupsBuf g_md5_groups_buf[64];
+}
+
+extern "C" int flacamd_md5_groups_device(int device, uint32_t ngroups, const flacamd_md5_group *groups, void *stream)
+{
+	if(!groups || ngroups == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= 64) return FLACAMD_E_NO_DEVICE;
+	size_t total = 0;
+	for(uint32_t g = 0; g < ngroups; g++) {
+		const flacamd_md5_group &q = groups[g];
+		if(!q.d_pcm || !q.h_start || !q.h_len || !q.d_digests || q.nclips == 0 || q.channels == 0 || q.channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
+		if(q.pcm_format != FLACAMD_PCM_S32 && q.pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+		total += ((size_t)q.nclips + 63u) & ~(size_t)63u;   // every group starts a wave of its own
+	}
+	if(total > 0xffffffffull) return FLACAMD_E_CAPACITY;
+	if(hipSetDevice(device) != hipSuccess) return FLACAMD_E_DEVICE;
+	std::lock_guard<std::mutex> hold(g_md5_groups_lock);
+	Md5GroupsBuf &b = g_md5_groups_buf[device];
+	const size_t bytes = total * sizeof(FaMd5Rec);
+	if(b.cap < bytes) {   // grow-only staging: none of this on the steady path
+		if(b.h) (void)hipHostFree(b.h);
+		if(b.d) (void)hipFree(b.d);
+		b.h = 0; b.d = 0; b.cap = 0;
+		if(hipHostMalloc(&b.h, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&b.d, bytes) != hipSuccess) {
+			if(b.h) (void)hipHostFree(b.h);
+			b.h = 0; (void)hipGetLastError();
+			return FLACAMD_E_OUT_OF_MEMORY;
+		}
+		b.cap = bytes;
+	}
+	FaMd5Rec *r = (FaMd5Rec*)b.h;
+	size_t at = 0;
+	for(uint32_t g = 0; g < ngroups; g++) {
+		const flacamd_md5_group &q = groups[g];
+		for(uint32_t i = 0; i < q.nclips; i++, at++) {
+			r[at].pcm = q.d_pcm; r[at].digest = q.d_digests + (size_t)i * 16u; r[at].s0 = q.h_start[i]; r[at].s1 = q.h_start[i] + q.h_len[i];
+			r[at].fmt = (uint32_t)q.pcm_format; r[at].channels = q.channels; r[at].bps = q.bits_per_sample; r[at].pad = 0;
+		}
+		for(; at & 63u; at++) memset(&r[at], 0, sizeof r[at]);
+	}
+	hipStream_t st = (hipStream_t)stream;
+	if(hipMemcpyAsync(b.d, b.h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
+	hipLaunchKernelGGL(fa_md5_multi_kernel, dim3((uint32_t)(total / 64u)), dim3(64), 0, st, (const FaMd5Rec*)b.d, (uint32_t)total);
+	return hipGetLastError() == hipSuccess ? FLACAMD_OK : FLACAMD_E_DEVICE;
 }

@@ -31,6 +31,26 @@ class Params(C.Structure):
         ("apod_type", C.c_uint32 * 32), ("apod_param", C.c_float * 32)]
 
 
+class Md5Group(C.Structure):
+    """flacamd_md5_group"""
+    _fields_ = [("d_pcm", C.c_void_p), ("pcm_format", C.c_int), ("channels", C.c_uint32), ("bits_per_sample", C.c_uint32), ("nclips", C.c_uint32),
+                ("h_start", C.c_void_p), ("h_len", C.c_void_p), ("d_digests", C.c_void_p)]
+
+
+def md5_groups_device(device, groups, stream=None):
+    """groups: list of (d_pcm_ptr, fmt, channels, bits_per_sample, starts, lengths, d_digests_ptr).  One launch hashes every clip
+    of every group (flacamd_md5_groups_device); asynchronous on `stream`."""
+    arr = (Md5Group * len(groups))()
+    keep = []
+    for g, (ptr, fmt, ch, bps, starts, lens, dig) in zip(arr, groups):
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        ln = np.ascontiguousarray(lens, dtype=np.uint64)
+        keep += [st, ln]
+        g.d_pcm, g.pcm_format, g.channels, g.bits_per_sample, g.nclips = ptr, fmt, ch, bps, len(st)
+        g.h_start, g.h_len, g.d_digests = st.ctypes.data, ln.ctypes.data, dig
+    _check(lib().flacamd_md5_groups_device(device, len(groups), arr, C.c_void_p(stream)), "flacamd_md5_groups_device")
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, where, detail=""):
         self.code = code
@@ -228,6 +248,11 @@ class Encoder:
             raise OutputTooSmall(int(total.value))   # frames beyond the verbatim bound: call again with that many bytes
         _check(rc, "flacamd_encode_streams_device")
         return int(total.value)
+
+    def use_digests(self, d_digests_ptr, ready_event=None):
+        """The next encode_clips_device call takes its clips' MD5 digests from device memory (flacamd_encoder_use_digests);
+        ready_event: raw hipEvent_t handle (int) waited for before the stream heads are written."""
+        _check(self._lib.flacamd_encoder_use_digests(self._h, C.c_void_p(d_digests_ptr), C.c_void_p(ready_event)), "flacamd_encoder_use_digests")
 
     def encode_clips_device(self, d_pcm_ptr, fmt, starts, lengths, d_out_ptr, out_cap, stream=None):
         """A batch of clips as complete streams assembled on the device (flacamd_encode_clips_device).  Returns the

@@ -152,6 +152,21 @@ int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_pcm, int pcm
 int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint32_t nclips,
 	const uint64_t *h_start, const uint64_t *h_len, void *d_out, size_t out_cap, uint64_t *h_stream_off, uint64_t *h_total_bytes, void *stream);
 
+/* The digests of several clip batches in ONE pass: every clip of every group is a lane of the same kernel launch, so the
+ * whole hash takes as long as the longest clip (a digest is a serial chain, md5.c:216-420) instead of that once per
+ * group.  d_digests of group g receives nclips x 16 bytes (device memory).  Asynchronous on `stream`; the tables are
+ * staged in buffers that belong to the device (calls for one device must not overlap).  Hand the result to the next
+ * flacamd_encode_clips_device call of a group's encoder with flacamd_encoder_use_digests. */
+typedef struct {
+	const void *d_pcm; int pcm_format; uint32_t channels, bits_per_sample, nclips;
+	const uint64_t *h_start, *h_len;   /* as for flacamd_encode_clips_device */
+	uint8_t *d_digests;
+} flacamd_md5_group;
+int flacamd_md5_groups_device(int device, uint32_t ngroups, const flacamd_md5_group *groups, void *stream);
+/* The next flacamd_encode_clips_device call of this encoder takes its clips' digests from d_digests instead of computing
+ * them; ready_event (a hipEvent_t, may be null) is waited for on the call's stream before the stream heads are written. */
+int flacamd_encoder_use_digests(flacamd_encoder *e, const uint8_t *d_digests, void *ready_event);
+
 /* Same with host buffers: copies PCM in, frames and sizes out (PCIe inclusive). */
 int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
