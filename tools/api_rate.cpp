@@ -45,6 +45,7 @@ static double run_decode(const std::vector<uint8_t> &stream, int md5, uint64_t e
 	Source src = { stream.data(), stream.size(), 0, 0, 0 };
 	FLAC__StreamDecoder *d = FLAC__stream_decoder_new();
 	FLAC__stream_decoder_set_md5_checking(d, md5);
+	if(getenv("API_RATE_DEC_BATCH")) flacamd_stream_decoder_set_batch_frames(d, (unsigned)atoi(getenv("API_RATE_DEC_BATCH")));
 	if(FLAC__stream_decoder_init_stream(d, on_read, 0, 0, 0, 0, on_frame, 0, on_error, &src) != FLAC__STREAM_DECODER_INIT_STATUS_OK) { fprintf(stderr, "decoder init failed\n"); exit(2); }
 	const double t0 = now();
 	if(!FLAC__stream_decoder_process_until_end_of_stream(d)) { fprintf(stderr, "decode failed\n"); exit(2); }
