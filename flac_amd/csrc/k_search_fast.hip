@@ -102,8 +102,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 	uint32_t *cqp = (uint32_t*)(ckey + cg);                            // [cg][HIST/2] coefficient pairs for the two-tap instruction
 	uint32_t *chdr = cqp + (size_t)cg * (HIST / 2);                    // [cg] candidate headers
 	uint32_t *cinfo = chdr + cg;                                       // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
-	uint32_t *cpo = cinfo + cg;                                        // [cg] best partition order | rice2 << 8
-	uint8_t *kbuf = (uint8_t*)(cpo + cg);                              // [cg][64] Rice parameters at the candidate's best order
+	uint32_t *cpo = cinfo + cg;                                        // [cg] best partition order
 
 	const bool active = i0 < n;
 	// samples and coefficients fit 16 bits: two taps per instruction.  The side channel of a 16-bit
@@ -365,66 +364,103 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		__syncthreads();
 		SF_STAMP(3);
 
-		// ---- one wave per candidate.  Sums of every partition order by in-register doubling steps: after
-		// step l every lane holds the sum of its aligned block of 2^l finest partitions.  Every lane prices
-		// two partitions: its finest one (level 0) and, for lane L != 0, block L >> lv of level lv = ctz(L) + 1,
-		// whose sum it picks up as the chain passes that level (each block of each level has exactly one such
-		// lane: 63 coarser partitions for 63 lanes, nothing goes through memory).  Bits per order: the
-		// level-lv lanes are the lanes congruent to 2^(lv-1) modulo 2^lv, so one butterfly over the
-		// distances 32 .. 1 walks lane 0 through the totals of levels 6, 6+5, ... 6+..+1.  Then the best
-		// order (searched max -> min, strict '<') and the subframe estimate.
-		const uint32_t lvB = lane ? (uint32_t)__ffs((int)lane) : 7u;          // level of this lane's second partition (lane 0: none)
-		const bool hasB = lane != 0u && lane < parts0;
-		const uint32_t pB = hasB ? lane >> lvB : 0u;                           // its index among the partitions of that level
-		const uint32_t poA = maxpo_f, poB = hasB ? maxpo_f - lvB : 0u;
-		for(uint32_t ci = wave; ci < ((c.debug & 2u) ? 0u : gn); ci += SF_WAVES) {
-			// the same for every lane: keep them in scalar registers, so that what depends on them branches without masks
-			const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)chdr[ci]), info = (uint32_t)__builtin_amdgcn_readfirstlane((int)cinfo[ci]);
-			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
-			const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
-			const uint32_t lvl_c = maxpo_f - maxpo_c;
-			const SUM *row = psum + (size_t)ci * SF_ROW;
-			SUM vA = (lane < parts0) ? row[lane] : (SUM)0;
-			// a value at the candidate's own finest order is wrapped to 32 bits when the reference's
-			// accumulator there is 32 bits wide; coarser orders add the wrapped values
-			if(narrow_c && lvl_c == 0u) vA &= (SUM)0xffffffffull;
-			SUM v = vA, vB = 0;
-			// (levels above the frame's finest order only add the zeros of the unused lanes: harmless, and cheaper than branching)
-#define SF_CHAIN(L) do { v = block_sum_step<L>(v); if(narrow_c && lvl_c == (uint32_t)(L)) v &= (SUM)0xffffffffull; if(lvB == (uint32_t)(L)) vB = v; } while(0)
-			SF_CHAIN(1); SF_CHAIN(2); SF_CHAIN(3); SF_CHAIN(4); SF_CHAIN(5); SF_CHAIN(6);
-#undef SF_CHAIN
-			uint32_t kA, estA, kB, estB;
-			sf_price<SUM>(vA, (n >> poA) - (lane == 0 ? order : 0u), poA == 0, FA_CAND_K(hdr), c.k_limit, kA, estA);   // order 0 takes the suggested parameter, stream_encoder.c:3982-4029
-			sf_price<SUM>(vB, (n >> poB) - (pB == 0 ? order : 0u), poB == 0, FA_CAND_K(hdr), c.k_limit, kB, estB);
-			if(!(lane < parts0 && poA <= maxpo_c && poA >= minpo_c)) estA = 0;
-			if(!(hasB && poB <= maxpo_c && poB >= minpo_c)) estB = 0;
-			// level totals: run[j] = bits of levels 6, 6+5, ... down to level 6 - j (read from lane 0 after each step)
-			uint32_t run[6], tA = estA, tB = estB;
-#define SF_TOT(D, J) do { tA = class_sum_step<D>(tA); tB = class_sum_step<D>(tB); run[J] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tB); } while(0)
-			SF_TOT(32, 0); SF_TOT(16, 1); SF_TOT(8, 2); SF_TOT(4, 3); SF_TOT(2, 4); SF_TOT(1, 5);
-#undef SF_TOT
-			const uint32_t totA = (uint32_t)__builtin_amdgcn_readfirstlane((int)tA);
-			// bits of level lv (partition order maxpo_f - lv); orders are tried from the candidate's highest down, strict '<'
-			const uint32_t lvbits[7] = { totA, run[5] - run[4], run[4] - run[3], run[3] - run[2], run[2] - run[1], run[1] - run[0], run[0] };
-			const uint32_t lv_lo = maxpo_f - maxpo_c, lv_hi = maxpo_f - minpo_c;
-			uint32_t best = 0, bestlv = 0; bool have = false;
-#pragma unroll
-			for(int lv = 0; lv < 7; lv++) {
-				if((uint32_t)lv >= lv_lo && (uint32_t)lv <= lv_hi) {
-					const uint32_t b = 6u + lvbits[lv];
-					if(!have || b < best) { best = b; bestlv = (uint32_t)lv; have = true; }
+		// ---- eight threads per candidate, thread j of a group taking the finest partitions 8j .. 8j + 7 of its
+		// candidate's row: it adds them up to the 4 + 2 + 1 partitions of the next three orders that lie inside its
+		// span and prices all fifteen.  The partitions of the three coarsest orders (4 + 2 + 1 more) span several
+		// threads: their sums come from three exchange steps inside the group (lane ^ 1, lane ^ 2, lane <-> 7 - lane)
+		// and are priced by the lanes {1, 3, 4, 6}, {2, 5} and {7} as the chain passes their level - every pair
+		// and every half of the group holds exactly one of these lanes.  Bits per order: plain sums over the
+		// group for the four inner levels; for the outer three the same exchange steps taken in the opposite
+		// order walk lane 0 through the totals of level 6, 6 + 5, 6 + 5 + 4.  Lane 0 of the group then picks the
+		// best order (searched max -> min, strict '<') and leaves estimate and order; the Rice parameters are
+		// not kept: the first wave works them out again for the one candidate that wins.
+		if(!(c.debug & 2u)) {
+			const uint32_t j = tid & 7u;
+			const uint32_t lvU = (0x64544540u >> (4u * j)) & 15u;                 // level of this lane's outer partition (lane 0: none)
+			const bool firstU = j == 1u || j == 2u || j == 7u;                     // ... and whether it is the first partition of that level
+			const bool in_frame = j * 8u < parts0;                                 // the span holds partitions of this frame
+			const int32_t room = (int32_t)parts0 - (int32_t)(j * 8u);             // finest partitions of the frame from the span's start on
+			for(uint32_t ci = tid >> 3; ci < gn; ci += SF_THREADS / 8u) {
+				const uint32_t hdr = chdr[ci], info = cinfo[ci];
+				const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
+				const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
+				const uint32_t lvl_c = maxpo_f - maxpo_c;
+				const uint32_t given_k = FA_CAND_K(hdr);
+				const SUM *row = psum + (size_t)ci * SF_ROW + j * 8u;
+				SUM f0[8], f1[4], f2[2], f3;
+				if(sizeof(SUM) == 4) {
+					const uint4 a = ((const uint4*)row)[0], b = ((const uint4*)row)[1];
+					f0[0] = (SUM)a.x; f0[1] = (SUM)a.y; f0[2] = (SUM)a.z; f0[3] = (SUM)a.w; f0[4] = (SUM)b.x; f0[5] = (SUM)b.y; f0[6] = (SUM)b.z; f0[7] = (SUM)b.w;
 				}
+				else {
+#pragma unroll
+					for(int i = 0; i < 8; i++) f0[i] = row[i];
+				}
+				// a value at the candidate's own finest order is wrapped to 32 bits when the reference's
+				// accumulator there is 32 bits wide; coarser orders add the wrapped values
+#define SF_WRAP(L, v) do { if(narrow_c && lvl_c == (uint32_t)(L)) (v) &= (SUM)0xffffffffull; } while(0)
+#pragma unroll
+				for(int i = 0; i < 8; i++) SF_WRAP(0, f0[i]);
+#pragma unroll
+				for(int i = 0; i < 4; i++) { f1[i] = f0[2*i] + f0[2*i+1]; SF_WRAP(1, f1[i]); }
+#pragma unroll
+				for(int i = 0; i < 2; i++) { f2[i] = f1[2*i] + f1[2*i+1]; SF_WRAP(2, f2[i]); }
+				f3 = f2[0] + f2[1]; SF_WRAP(3, f3);
+				SUM u = block_sum_step<1>(f3), vU; SF_WRAP(4, u); vU = u;
+				u = block_sum_step<2>(u); SF_WRAP(5, u); if(lvU == 5u) vU = u;
+				u = block_sum_step<3>(u); SF_WRAP(6, u); if(lvU == 6u) vU = u;
+#undef SF_WRAP
+				// bits of a partition of level L (partition order maxpo_f - L); the first partition of a level is `order` samples
+				// short, and order 0 takes the suggested parameter (stream_encoder.c:3982-4029)
+				auto bits = [&](SUM sum, uint32_t L, bool first) -> uint32_t {
+					uint32_t k, est;
+					sf_price<SUM>(sum, (dps0 << L) - (first ? order : 0u), first && L == maxpo_f, given_k, c.k_limit, k, est);
+					return est;
+				};
+				uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, eU;
+				if(parts0 >= 8u) {
+#pragma unroll
+					for(int i = 0; i < 8; i++) e0 += bits(f0[i], 0u, i == 0 && j == 0u);
+#pragma unroll
+					for(int i = 0; i < 4; i++) e1 += bits(f1[i], 1u, i == 0 && j == 0u);
+#pragma unroll
+					for(int i = 0; i < 2; i++) e2 += bits(f2[i], 2u, i == 0 && j == 0u);
+					e3 = bits(f3, 3u, j == 0u);
+				}
+				else {
+					// fewer than eight finest partitions: the span reaches beyond the frame
+#pragma unroll
+					for(int i = 0; i < 8; i++) { const uint32_t e = bits(f0[i], 0u, i == 0 && j == 0u); e0 += (i < room) ? e : 0u; }
+#pragma unroll
+					for(int i = 0; i < 4; i++) { const uint32_t e = bits(f1[i], 1u, i == 0 && j == 0u); e1 += (2 * i < room) ? e : 0u; }
+#pragma unroll
+					for(int i = 0; i < 2; i++) { const uint32_t e = bits(f2[i], 2u, i == 0 && j == 0u); e2 += (4 * i < room) ? e : 0u; }
+					e3 = bits(f3, 3u, j == 0u);
+				}
+				eU = bits(vU, lvU, firstU);
+				if(!in_frame) { e0 = 0; e1 = 0; e2 = 0; e3 = 0; }
+				if(!in_frame || lvU == 0u) eU = 0;
+				// totals over the group
+				e0 = block_sum_step<1>(e0); e1 = block_sum_step<1>(e1); e2 = block_sum_step<1>(e2); e3 = block_sum_step<1>(e3);
+				e0 = block_sum_step<2>(e0); e1 = block_sum_step<2>(e1); e2 = block_sum_step<2>(e2); e3 = block_sum_step<2>(e3);
+				e0 = block_sum_step<3>(e0); e1 = block_sum_step<3>(e1); e2 = block_sum_step<3>(e2); e3 = block_sum_step<3>(e3);
+				const uint32_t r1 = eU + row_partner<4>(eU);          // lane 0: level 6
+				const uint32_t r2 = r1 + row_partner<2>(r1);          //         levels 6 + 5
+				const uint32_t r3 = r2 + row_partner<1>(r2);          //         levels 6 + 5 + 4
+				const uint32_t lvbits[7] = { e0, e1, e2, e3, r3 - r2, r2 - r1, r1 };
+				const uint32_t lv_lo = maxpo_f - maxpo_c, lv_hi = maxpo_f - minpo_c;
+				uint32_t best = 0, bestlv = 0; bool have = false;
+#pragma unroll
+				for(int lv = 0; lv < 7; lv++) {
+					const uint32_t b = 6u + lvbits[lv];
+					const bool take = ((uint32_t)lv - lv_lo <= lv_hi - lv_lo) && (!have || b < best);
+					best = take ? b : best; bestlv = take ? (uint32_t)lv : bestlv; have = have || take;
+				}
+				const uint32_t bestpo = maxpo_f - bestlv;
+				uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
+				if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
+				if(j == 0u) { ckey[ci] = ((unsigned long long)est << 32) | (unsigned long long)(cb + ci); cpo[ci] = bestpo; }
 			}
-			const uint32_t bestpo = maxpo_f - bestlv;
-			uint32_t est = 8u + wasted + order * bps + best;                         // stream_encoder.c:3550
-			if(FA_CAND_KIND(hdr)) est = 8u + wasted + 9u + order * (FA_CAND_PREC(hdr) + bps) + best; // :3636
-			// park the parameters of the best order: entry p of the row is partition p
-			const uint32_t bl = maxpo_f - bestpo;
-			const bool own_b = bl == 0u ? (lane < parts0) : (hasB && lvB == bl);
-			const uint32_t kb = bl == 0u ? kA : kB;
-			if(own_b) kbuf[(size_t)ci * SF_PARTS + (bl == 0u ? lane : pB)] = (uint8_t)kb;
-			const uint32_t big = __any((own_b && kb >= 15u) ? 1 : 0) ? 1u : 0u;
-			if(lane == 0) { ckey[ci] = ((unsigned long long)est << 32) | (unsigned long long)(cb + ci); cpo[ci] = bestpo | (big << 8); }
 		}
 		SF_STAMP(4);
 		__syncthreads();
@@ -438,12 +474,26 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			const uint32_t est = (uint32_t)(bk >> 32), widx = (uint32_t)bk - cb;
 			// earlier groups hold earlier candidates: replace only when strictly smaller
 			if(!have_best || est < best_est) {
-				const uint32_t pw = cpo[widx];
-				have_best = 1; best_est = est; best_cand = cb + widx; best_po = pw & 255u; best_rice2 = pw >> 8;
+				have_best = 1; best_est = est; best_cand = cb + widx; best_po = cpo[widx];
 				best_hdr = chdr[widx]; best_q = (lane < (uint32_t)HIST) ? cq[widx * HIST + lane] : 0;
-				// Rice parameters of the winner, spread to the finest configured order so that the
-				// pack stage can index them by sample position alone
-				for(uint32_t pe = lane; pe < parts_cap; pe += 64u) win->k[pe] = kbuf[(size_t)widx * SF_PARTS + (pe >> (emax - best_po))];
+				// Rice parameters of the winner at its best order: lane p starts from finest partition p, best_lv doubling steps
+				// leave every lane with the sum of the partition it lies in
+				const uint32_t info = cinfo[widx], order = info & 255u, maxpo_c = (info >> 8) & 15u;
+				const bool narrow_c = sizeof(SUM) == 8 && ((info >> 16) & 1u);
+				const uint32_t lvl_c = maxpo_f - maxpo_c, best_lv = maxpo_f - best_po;
+				SUM v = (lane < parts0) ? psum[(size_t)widx * SF_ROW + lane] : (SUM)0;
+				if(narrow_c && lvl_c == 0u) v &= (SUM)0xffffffffull;
+#define SF_CHAIN(L) do { if(best_lv >= (uint32_t)(L)) { v = block_sum_step<L>(v); if(narrow_c && lvl_c == (uint32_t)(L)) v &= (SUM)0xffffffffull; } } while(0)
+				SF_CHAIN(1); SF_CHAIN(2); SF_CHAIN(3); SF_CHAIN(4); SF_CHAIN(5); SF_CHAIN(6);
+#undef SF_CHAIN
+				uint32_t kw, estw;
+				sf_price<SUM>(v, (n >> best_po) - ((lane >> best_lv) == 0u ? order : 0u), best_po == 0u, FA_CAND_K(best_hdr), c.k_limit, kw, estw);
+				best_rice2 = __any((lane < parts0 && kw >= 15u) ? 1 : 0) ? 1u : 0u;
+				// ... spread to the finest configured order so that the pack stage can index them by sample position alone
+				for(uint32_t pe = 0; pe < parts_cap; pe += 64u) {
+					const uint32_t kk = (uint32_t)__shfl((int)kw, (int)((((pe + lane) >> (emax - best_po)) << best_lv) & 63u), 64);
+					if(pe + lane < parts_cap) win->k[pe + lane] = (uint8_t)kk;
+				}
 			}
 		}
 		if(cb + cg < ncand) __syncthreads();
@@ -497,7 +547,6 @@ extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum6
 	b += (size_t)cg * 8u;                            // ckey
 	b += (size_t)cg * (HIST / 2) * 4u;               // cqp
 	b += (size_t)cg * 4u * 3u;                       // chdr, cinfo, cpo
-	b += (size_t)cg * SF_PARTS;                      // kbuf
 	return (b + 15u) & ~(size_t)15u;
 }
 
