@@ -46,11 +46,14 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 {
 	if(sizeof(SUM) == 4) {
 		const uint32_t s32 = (uint32_t)sum;
-		k = s32 > nsamp ? (uint32_t)__clz((int)nsamp) - (uint32_t)__clz((int)s32) : 0u;   // nsamp << k now has the bit length of sum
+		// nsamp << k has the bit length of sum (k = 0 when sum is the shorter; "| 1" gives a zero sum a length without changing any other)
+		const int32_t d = __builtin_clz(nsamp) - __builtin_clz(s32 | 1u);
+		k = (uint32_t)(d > 0 ? d : 0);
 		k += ((nsamp << k) < s32) ? 1u : 0u;
-		if(k >= k_limit) k = k_limit - 1u;
+		k = k < k_limit - 1u ? k : k_limit - 1u;
 		if(use_given_k) k = given_k;
-		est = 4u + (1u + k) * nsamp + (k ? (s32 >> (k - 1u)) : (s32 << 1)) - (nsamp >> 1);
+		// sum >> (k - 1), or sum << 1 for k = 0: the low word of the 33-bit 2 * sum shifted right by k
+		est = (uint32_t)__umul24(k, nsamp) + __builtin_amdgcn_alignbit(s32 >> 31, s32 << 1, k) + (4u + nsamp - (nsamp >> 1));
 	}
 	else {
 		const unsigned long long s64 = (unsigned long long)sum;
