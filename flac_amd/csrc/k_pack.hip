@@ -543,11 +543,14 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 	if(lane == 0) { rec->assignment = a; w.assignment[f] = a; }
 }
 
-// 256 threads x 16 samples capped at 128 registers: four workgroups per CU, 0.96 ms per hour of audio (512 x 8 at two /
-// three workgroups per CU: 1.30 / 1.03 ms; tighter caps spill more than the extra workgroups hide).
-// PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), kept as one register per wide sample
+// 256 threads x 16 samples capped at 128 registers: four workgroups per CU (512 x 8 at two / three workgroups per CU
+// was a third slower).
+// PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), kept as one register per wide sample; that one fits five
+// workgroups per CU with ten registers in scratch memory (0.90 -> 0.80 ms per hour of audio: the kernel is a chain of
+// load, scan, emission, look-back, CRC and flush with barriers between, which more resident workgroups hide; at six,
+// with 46 registers spilled, it takes 1.02 ms)
 template<int NSUB, bool PACKED16>
-__global__ void __launch_bounds__(PF_THREADS, 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+__global__ void __launch_bounds__(PF_THREADS, PACKED16 ? 5 : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
