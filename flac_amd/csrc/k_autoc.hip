@@ -38,6 +38,9 @@ __device__ __forceinline__ uint32_t raw_get(const Raw16 &r, int j)
 template<int LAG>
 __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
 {
+	// These waves are few (one lane per signal) and each is a long serial chain: they go first wherever they share a SIMD
+	// with the preparation kernel's many short ones, which fill the gaps
+	__builtin_amdgcn_s_setprio(3);
 	const uint32_t lane = threadIdx.x;
 	const uint32_t g = blockIdx.x * 64u + lane;
 	const bool active = g < c.G;

@@ -103,12 +103,13 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 
 struct PrepFastShared { unsigned long long err[4][5]; uint32_t orv[4], ne[4]; };
 
-__global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
+__global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w, uint32_t frame0, uint32_t only_short)
 {
 	__shared__ PrepFastShared sh;
 	__shared__ uint32_t s_fps[4][5][64];   // per signal and difference order: sums over the finest partitions (FaCfg::fixed_psum)
-	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t f = frame0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t n = fa_frame_len(c, w, f);
+	if(only_short && n == c.N) return;     // full-length frames went to the kernel below
 	if(c.fixed_psum) for(uint32_t t = tid; t < 4u * 5u * 64u; t += 256u) (&s_fps[0][0][0])[t] = 0u;
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
 	const uint32_t i0 = tid * PP_CH;
@@ -251,16 +252,143 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 	}
 }
 
+// The same for full-length frames of batches whose per-partition sums are wanted (FaCfg::fixed_psum, blocks a multiple
+// of 16 samples, at most 64 finest partitions): the per-thread sums go to the partition table in LDS and nowhere else -
+// a frame's totals are the sums of its table rows less the head terms that the two conventions count differently
+// (the table leaves out sample i < k at order k, fixed.c:229-243 leaves out the first four samples at every order) -
+// so no thread carries the twenty sums of the four signals: 64 registers, eight waves per SIMD.  This kernel runs beside
+// the autocorrelation kernel, whose long-lived waves hold three fifths of the register file: what decides its speed is
+// how many of its own waves fit next to them.
+__global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
+{
+	__shared__ uint32_t s_fps[4][5][64];
+	__shared__ uint32_t s_head[4][5], s_orv[4], s_ne[4];
+	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t n = fa_frame_len(c, w, f);
+	if(n != c.N) return;                   // a short block: the kernel above takes it
+	for(uint32_t t = tid; t < 4u * 5u * 64u; t += 256u) (&s_fps[0][0][0])[t] = 0u;
+	if(tid < 4u) { s_orv[tid] = 0; s_ne[tid] = 0; }
+	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
+	const uint32_t i0 = tid * PP_CH;
+	const bool active = i0 < n;
+
+	uint32_t raw[PP_HIST + PP_CH];
+#pragma unroll
+	for(int j = 0; j < (PP_HIST + PP_CH) / 4; j++) {
+		const int32_t rel = (int32_t)i0 - PP_HIST + 4 * j;
+		uint4 v = make_uint4(0u, 0u, 0u, 0u);
+		if(active && rel >= 0) v = *(const uint4*)(p + rel);
+		raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
+	}
+	const uint32_t first = p[0];
+	const uint32_t tz = (uint32_t)__ffs((int)n) - 1u, maxpo = tz < c.max_po ? tz : c.max_po;
+	const uint32_t part = i0 / (n >> maxpo);      // < 64 (host check)
+	__syncthreads();
+
+	uint32_t vo[8];
+#pragma unroll
+	for(int s = 0; s < 4; s++) {
+		auto sig = [&](uint32_t lr) -> uint32_t {
+			const int32_t l = (int32_t)(int16_t)(lr & 0xffffu), r = (int32_t)lr >> 16;
+			return (uint32_t)(s == 0 ? l : s == 1 ? r : s == 2 ? (l + r) >> 1 : l - r);
+		};
+		const uint32_t B = 0x80000000u;
+		const uint32_t x0 = sig(first);
+		uint32_t o = 0, diff = 0, mag = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+		// (every signal unpacks the words again: kept unpacked for all four, they would take forty registers)
+#pragma unroll
+		for(int j = 0; j < PP_HIST + PP_CH; j++) asm volatile("" : "+v"(raw[j]));
+		const uint32_t h1 = sig(raw[3]), h2 = sig(raw[2]), h3 = sig(raw[1]), h4 = sig(raw[0]);
+		uint32_t pxb = h1 ^ B, pd1, pd2, pd3;
+		{
+			const uint32_t a1 = h1 - h2, a2 = h2 - h3, a3 = h3 - h4;   // d1(-1), d1(-2), d1(-3)
+			const uint32_t b1 = a1 - a2, b2 = a2 - a3;                  // d2(-1), d2(-2)
+			pd1 = a1 ^ B; pd2 = b1 ^ B; pd3 = (b1 - b2) ^ B;
+		}
+#pragma unroll
+		for(int q = 0; q < PP_CH; q++) {
+			const uint32_t a = sig(raw[PP_HIST + q]), ab = a ^ B;
+			const uint32_t d1b = (ab - pxb) ^ B, d2b = (d1b - pd1) ^ B, d3b = (d2b - pd2) ^ B;   // the biases cancel in each difference
+			e0 = sad_u32(ab, B, e0); e1 = sad_u32(ab, pxb, e1); e2 = sad_u32(d1b, pd1, e2); e3 = sad_u32(d2b, pd2, e3); e4 = sad_u32(d3b, pd3, e4);
+			o |= a; diff |= a ^ x0;
+			if(s == 3) mag |= a ^ (uint32_t)((int32_t)a >> 31);
+			pxb = ab; pd1 = d1b; pd2 = d2b; pd3 = d3b;
+		}
+		if(tid == 0) {
+			// samples 0..3 of the frame: history is zero, so d_k(q) is the k-th difference of (0, 0, 0, 0, x0, x1, x2, x3)
+			const uint32_t s0 = sig(raw[4]), s1 = sig(raw[5]), s2 = sig(raw[6]), s3 = sig(raw[7]);
+			const uint32_t f1[4] = { s0, s1 - s0, s2 - s1, s3 - s2 };
+			const uint32_t f2[4] = { f1[0], f1[1] - f1[0], f1[2] - f1[1], f1[3] - f1[2] };
+			const uint32_t f3[4] = { f2[0], f2[1] - f2[0], f2[2] - f2[1], f2[3] - f2[2] };
+			const uint32_t f4[4] = { f3[0], f3[1] - f3[0], f3[2] - f3[1], f3[3] - f3[2] };
+			auto mg = [](uint32_t v) { const int32_t t = (int32_t)v; return (uint32_t)(t < 0 ? -t : t); };
+			// the table's convention: sample i counts at order k when i >= k
+			e1 -= mg(f1[0]); e2 -= mg(f2[0]) + mg(f2[1]); e3 -= mg(f3[0]) + mg(f3[1]) + mg(f3[2]); e4 -= mg(f4[0]) + mg(f4[1]) + mg(f4[2]) + mg(f4[3]);
+			// ... and what the frame totals leave out besides: samples k .. 3
+			s_head[s][0] = mg(s0) + mg(s1) + mg(s2) + mg(s3); s_head[s][1] = mg(f1[1]) + mg(f1[2]) + mg(f1[3]);
+			s_head[s][2] = mg(f2[2]) + mg(f2[3]); s_head[s][3] = mg(f3[3]); s_head[s][4] = 0u;
+		}
+		if(active) {
+			atomicAdd(&s_fps[s][0][part], e0); atomicAdd(&s_fps[s][1][part], e1); atomicAdd(&s_fps[s][2][part], e2);
+			atomicAdd(&s_fps[s][3][part], e3); atomicAdd(&s_fps[s][4][part], e4);
+		}
+		// bit 0: differs from the first sample somewhere; bit 1 (side signal of 16-bit channels, nominally 17 bits): a sample outside the 16-bit range
+		vo[s] = active ? o : 0u;
+		vo[4 + s] = active ? ((diff ? 1u : 0u) | ((s == 3 && (mag >> 15)) ? 2u : 0u)) : 0u;
+	}
+	wave_combine<8, true>(vo, lane);     // lane l: OR of vo[l >> 3]
+	if((lane & 7u) == 0) { const uint32_t idx = lane >> 3; if(idx < 4u) atomicOr(&s_orv[idx], vo[0]); else atomicOr(&s_ne[idx - 4u], vo[0]); }
+	__syncthreads();
+
+	{
+		uint32_t *dst = w.fixed_psum + (size_t)f * c.nsig * 320u;
+		for(uint32_t t = tid; t < c.nsig * 320u; t += 256u) dst[t] = (&s_fps[0][0][0])[t];   // signal-major in both
+	}
+	// eight threads per (signal, order): the total of its 64 table entries
+	const uint32_t pair = tid >> 3, j = tid & 7u;
+	if(pair < c.nsig * 5u) {
+		const uint32_t s = pair / 5u, k = pair - s * 5u, g = f * c.nsig + s;
+		const uint4 a = ((const uint4*)&s_fps[s][k][8u * j])[0], b = ((const uint4*)&s_fps[s][k][8u * j])[1];
+		unsigned long long v = (unsigned long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+		v += (unsigned long long)__shfl_xor((long long)v, 1, 64); v += (unsigned long long)__shfl_xor((long long)v, 2, 64); v += (unsigned long long)__shfl_xor((long long)v, 4, 64);
+		if(j == 0u) {
+			const uint32_t all = s_orv[s];
+			const uint32_t wasted = all ? (uint32_t)__ffs((int)all) - 1u : 0u;
+			v = (v - s_head[s][k]) >> wasted;
+			if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
+			w.fixed_err[(size_t)k * c.G + g] = v;
+			if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(((s_ne[s] & 1u) ? 0u : 1u) | ((s_ne[s] & 2u) ? 0u : 2u)); }   // bit 0: constant, bit 1: every sample fits 16 bits
+		}
+	}
+}
+
 // 16-bit stereo (left/right, plus mid/side when analysed) with blocks of at most 256 x 16 samples
 extern "C" int fa_prep_fast_ok(const void *pcm, const FaCfg *c)
 {
 	return c->channels == 2u && c->pcm_format == FLACAMD_PCM_S16 && c->N <= 256u * PP_CH && (c->N % 4u) == 0 && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x2000u);
 }
 
+// ... of which the full-length frames can take the kernel that keeps its sums in the partition table
+static int fa_prep_lean_ok(const FaCfg *c)
+{
+	if(!c->fixed_psum || (c->N % PP_CH) != 0 || (c->debug & 0x100000u)) return 0;
+	uint32_t tz = 0;
+	while(!((c->N >> tz) & 1u)) tz++;
+	const uint32_t maxpo = tz < c->max_po ? tz : c->max_po;
+	return maxpo <= 6u;
+}
+
 extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
 	if(fa_prep_fast_ok(pcm, c)) {
-		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
+		if(fa_prep_lean_ok(c)) {
+			hipLaunchKernelGGL(fa_prep_stereo16_lean_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
+			// short blocks: anywhere in a batch of several streams, else the last frame at most
+			if(c->multi) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, 0u, 1u);
+			else if(c->last_n != c->N) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, c->F - 1u, 1u);
+			return;
+		}
+		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, 0u, 0u);
 		return;
 	}
 	if(c->spill) { hipLaunchKernelGGL(fa_prep_kernel<true>, dim3(c->G), dim3(256), 0, st, pcm, *c, *w); return; }

@@ -233,12 +233,13 @@ def test_stress_signals_on_the_register_resident_path(gpu_engine, kind, level, b
         enc.close()
 
 
-@pytest.mark.parametrize("flag", [0x80000, 0x40000, 0xC0000])
+@pytest.mark.parametrize("flag", [0x80000, 0x40000, 0xC0000, 0x100000])
 def test_alternative_stage_arrangements_give_the_same_frames(gpu_engine, monkeypatch, flag):
-    """The register-resident kernels take two shortcuts that other configurations cannot: the pack kernel writes frames
-    at their final place (look-back over the frame sizes) instead of into slots for the gather kernel, and the search
-    kernel takes the fixed predictors' partition sums from the preparation pass instead of computing them.  The
-    development switches that turn each of them off must not change a byte."""
+    """The register-resident kernels take shortcuts that other configurations cannot: the pack kernel writes frames
+    at their final place (look-back over the frame sizes) instead of into slots for the gather kernel, the search
+    kernel takes the fixed predictors' partition sums from the preparation pass instead of computing them, and the
+    preparation kernel for full-length frames takes the frame totals from those partition sums.  The development
+    switches that turn each of them off must not change a byte."""
     from flac_amd import synth
     pcm = synth.music_like(3.0, seed=91).astype(np.int16)
     for level in (8, 5, 2):
