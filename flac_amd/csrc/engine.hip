@@ -19,7 +19,7 @@
 #endif
 
 extern "C" {
-void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
+void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, hipStream_t st_short);
 int fa_prep_fast_ok(const void *pcm, const FaCfg *c);
 int fa_search_fast_ok(const void *pcm, const FaCfg *c);
 void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st);
@@ -432,15 +432,16 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 	// prep and autocorrelation read the same PCM and do not depend on each other (the model stage
 	// rescales the sums by the wasted bits): side by side on two streams, joined before the model
 	const bool fork = c.max_lpc_order > 0 && !(c.debug & 0x10000u);
+	// the fixed predictors' partition sums are a by-product of the preparation kernel's difference pass: the search kernel need not redo it
+	c.fixed_psum = (e->work.fixed_psum && fa_prep_fast_ok(d_pcm, &c) && fa_search_fast_ok(d_pcm, &c) && !(c.debug & 0x40000u)) ? 1u : 0u;
 	if(fork) {
 		HIP_TRY(hipEventRecord(e->ev_fork, st));
 		HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
 		fa_launch_autoc(d_pcm, &c, &e->work, e->side);
-		HIP_TRY(hipEventRecord(e->ev_join, e->side));
 	}
-	// the fixed predictors' partition sums are a by-product of the preparation kernel's difference pass: the search kernel need not redo it
-	c.fixed_psum = (e->work.fixed_psum && fa_prep_fast_ok(d_pcm, &c) && fa_search_fast_ok(d_pcm, &c) && !(c.debug & 0x40000u)) ? 1u : 0u;
-	fa_launch_prep(d_pcm, &c, &e->work, st);
+	// (a short last block has a preparation kernel of its own: behind the autocorrelation kernel, which ends first)
+	fa_launch_prep(d_pcm, &c, &e->work, st, fork ? e->side : st);
+	if(fork) HIP_TRY(hipEventRecord(e->ev_join, e->side));
 	if(tm) (void)hipEventRecord(e->ev[1], st);
 	if(fork) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
 	else if(c.max_lpc_order > 0) fa_launch_autoc(d_pcm, &c, &e->work, st);

@@ -280,7 +280,6 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 		if(active && rel >= 0) v = *(const uint4*)(p + rel);
 		raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
 	}
-	const uint32_t first = p[0];
 	const uint32_t tz = (uint32_t)__ffs((int)n) - 1u, maxpo = tz < c.max_po ? tz : c.max_po;
 	const uint32_t part = i0 / (n >> maxpo);      // < 64 (host check)
 	__syncthreads();
@@ -293,8 +292,7 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 			return (uint32_t)(s == 0 ? l : s == 1 ? r : s == 2 ? (l + r) >> 1 : l - r);
 		};
 		const uint32_t B = 0x80000000u;
-		const uint32_t x0 = sig(first);
-		uint32_t o = 0, diff = 0, mag = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+		uint32_t o = 0, mag = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
 		// (every signal unpacks the words again: kept unpacked for all four, they would take forty registers)
 #pragma unroll
 		for(int j = 0; j < PP_HIST + PP_CH; j++) asm volatile("" : "+v"(raw[j]));
@@ -310,7 +308,7 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 			const uint32_t a = sig(raw[PP_HIST + q]), ab = a ^ B;
 			const uint32_t d1b = (ab - pxb) ^ B, d2b = (d1b - pd1) ^ B, d3b = (d2b - pd2) ^ B;   // the biases cancel in each difference
 			e0 = sad_u32(ab, B, e0); e1 = sad_u32(ab, pxb, e1); e2 = sad_u32(d1b, pd1, e2); e3 = sad_u32(d2b, pd2, e3); e4 = sad_u32(d3b, pd3, e4);
-			o |= a; diff |= a ^ x0;
+			o |= a;
 			if(s == 3) mag |= a ^ (uint32_t)((int32_t)a >> 31);
 			pxb = ab; pd1 = d1b; pd2 = d2b; pd3 = d3b;
 		}
@@ -332,9 +330,9 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 			atomicAdd(&s_fps[s][0][part], e0); atomicAdd(&s_fps[s][1][part], e1); atomicAdd(&s_fps[s][2][part], e2);
 			atomicAdd(&s_fps[s][3][part], e3); atomicAdd(&s_fps[s][4][part], e4);
 		}
-		// bit 0: differs from the first sample somewhere; bit 1 (side signal of 16-bit channels, nominally 17 bits): a sample outside the 16-bit range
+		// (side signal of 16-bit channels, nominally 17 bits: a sample outside the 16-bit range)
 		vo[s] = active ? o : 0u;
-		vo[4 + s] = active ? ((diff ? 1u : 0u) | ((s == 3 && (mag >> 15)) ? 2u : 0u)) : 0u;
+		vo[4 + s] = (active && s == 3 && (mag >> 15)) ? 2u : 0u;
 	}
 	wave_combine<8, true>(vo, lane);     // lane l: OR of vo[l >> 3]
 	if((lane & 7u) == 0) { const uint32_t idx = lane >> 3; if(idx < 4u) atomicOr(&s_orv[idx], vo[0]); else atomicOr(&s_ne[idx - 4u], vo[0]); }
@@ -351,13 +349,17 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 		const uint4 a = ((const uint4*)&s_fps[s][k][8u * j])[0], b = ((const uint4*)&s_fps[s][k][8u * j])[1];
 		unsigned long long v = (unsigned long long)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
 		v += (unsigned long long)__shfl_xor((long long)v, 1, 64); v += (unsigned long long)__shfl_xor((long long)v, 2, 64); v += (unsigned long long)__shfl_xor((long long)v, 4, 64);
+		// a signal is constant when no sample differs from the one before it: the first differences' row adds up to zero
+		const uint4 a1 = ((const uint4*)&s_fps[s][1][8u * j])[0], b1 = ((const uint4*)&s_fps[s][1][8u * j])[1];
+		uint32_t moves = a1.x | a1.y | a1.z | a1.w | b1.x | b1.y | b1.z | b1.w;
+		moves |= (uint32_t)__shfl_xor((int)moves, 1, 64); moves |= (uint32_t)__shfl_xor((int)moves, 2, 64); moves |= (uint32_t)__shfl_xor((int)moves, 4, 64);
 		if(j == 0u) {
 			const uint32_t all = s_orv[s];
 			const uint32_t wasted = all ? (uint32_t)__ffs((int)all) - 1u : 0u;
 			v = (v - s_head[s][k]) >> wasted;
 			if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
 			w.fixed_err[(size_t)k * c.G + g] = v;
-			if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(((s_ne[s] & 1u) ? 0u : 1u) | ((s_ne[s] & 2u) ? 0u : 2u)); }   // bit 0: constant, bit 1: every sample fits 16 bits
+			if(k == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)((moves ? 0u : 1u) | ((s_ne[s] & 2u) ? 0u : 2u)); }   // bit 0: constant, bit 1: every sample fits 16 bits
 		}
 	}
 }
@@ -378,14 +380,16 @@ static int fa_prep_lean_ok(const FaCfg *c)
 	return maxpo <= 6u;
 }
 
-extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
+// st_short: where the kernel for the short blocks of a batch goes when the full-length frames have their own (it may
+// be st; a different stream must be joined by the caller before the results are used)
+extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st, hipStream_t st_short)
 {
 	if(fa_prep_fast_ok(pcm, c)) {
 		if(fa_prep_lean_ok(c)) {
 			hipLaunchKernelGGL(fa_prep_stereo16_lean_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
 			// short blocks: anywhere in a batch of several streams, else the last frame at most
-			if(c->multi) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, 0u, 1u);
-			else if(c->last_n != c->N) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, c->F - 1u, 1u);
+			if(c->multi) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st_short, (const uint32_t*)pcm, *c, *w, 0u, 1u);
+			else if(c->last_n != c->N) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(1), dim3(256), 0, st_short, (const uint32_t*)pcm, *c, *w, c->F - 1u, 1u);
 			return;
 		}
 		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, 0u, 0u);
