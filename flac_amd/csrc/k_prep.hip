@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 	const uint32_t f = frame0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t n = fa_frame_len(c, w, f);
 	if(only_short && n == c.N) return;     // full-length frames went to the kernel below
+	if(only_short) __builtin_amdgcn_s_setprio(3);   // a few workgroups beside tens of thousands of the other kernel's: do not queue behind them for every instruction
 	if(c.fixed_psum) for(uint32_t t = tid; t < 4u * 5u * 64u; t += 256u) (&s_fps[0][0][0])[t] = 0u;
 	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
 	const uint32_t i0 = tid * PP_CH;
