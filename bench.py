@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
 
 # kernel that runs each timed stage for this workload (16-bit stereo, blocksize 4096)
 KERNEL_OF_STAGE = {"prep_beside_autoc": "fa_prep_stereo16_lean_kernel", "autoc_join_wait": "fa_autoc_ms16_kernel<13>", "model": "fa_model_kernel<12>",
-                   "search": "fa_search_fast_kernel<unsigned int, 1, 1>", "pack": "fa_pack_fast_kernel<2, true>", "gather": "fa_scan_kernel"}
+                   "search": "fa_search_fast_kernel<unsigned int, 1, 1>", "pack": "fa_pack_fast_kernel<2, true, true>", "gather": "fa_scan_kernel"}
 
 
 def pmc_traffic(kernel, minutes):

@@ -545,12 +545,14 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 
 // 256 threads x 16 samples capped at 128 registers: four workgroups per CU (512 x 8 at two / three workgroups per CU
 // was a third slower).
-// PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), kept as one register per wide sample; that one fits five
-// workgroups per CU with ten registers in scratch memory (0.90 -> 0.80 ms per hour of audio: the kernel is a chain of
-// load, scan, emission, look-back, CRC and flush with barriers between, which more resident workgroups hide; at six,
-// with 46 registers spilled, it takes 1.02 ms)
-template<int NSUB, bool PACKED16>
-__global__ void __launch_bounds__(PF_THREADS, PACKED16 ? 5 : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+// PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), fetched as one register per wide sample.
+// NARROW: no subframe of the stream can need the 64-bit prediction sum or samples beyond 24 bits (decided on the host).
+// The kernel is a chain of load, scan, emission, look-back, CRC and flush with barriers between, which more resident
+// workgroups hide.  With both (the 64-bit path is where the register count peaks: 105 against 89) it runs six
+// workgroups per CU with seven registers in scratch memory: 0.90 ms per hour of audio at four, 0.80 at five (nothing
+// spilled), 0.745 at six, 1.00 at eight (23 spilled).
+template<int NSUB, bool PACKED16, bool NARROW>
+__global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
@@ -593,26 +595,28 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? 5 : 4) fa_pack_fast_ker
 	}
 	const FrameHdrFields hf = fa_frame_header_fields(c, n, fa_frame_num(c, w, f));
 
-	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels.  16-bit stereo stays packed (left | right << 16,
-	// one register per wide sample) until a subframe's signal is formed from it: half the registers, and nothing spills
+	// ---- this thread's samples i0 - HIST .. i0 + PF_CH - 1 of both channels.  16-bit stereo is fetched packed (left | right << 16,
+	// one register per wide sample) by each subframe in turn, which forms its signal in the same registers: the second
+	// fetch hits the cache, and holding the words across the first subframe's arithmetic instead costs the registers that
+	// decide whether five workgroups fit a CU
 	constexpr bool packed16 = PACKED16;
 	int32_t xa[PACKED16 ? 1 : PF_W], xb[PACKED16 ? 1 : PF_W];
-	uint32_t raw[PACKED16 ? PF_W : 1];
-	if constexpr(PACKED16) {
+	auto fetch_packed = [&](const uint32_t *src, uint32_t (&raw)[PF_W]) {
 #pragma unroll
 		for(int j = 0; j < PF_W / 4; j++) {
 			const int32_t rel = (int32_t)i0 - HIST + 4 * j;
 			uint4 v = make_uint4(0u, 0u, 0u, 0u);
-			if(rel >= 0 && (uint32_t)rel + 4u <= n) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
+			if(rel >= 0 && (uint32_t)rel + 4u <= n) v = *(const uint4*)(src + base + (uint32_t)rel);
 			else if(rel >= 0 && (uint32_t)rel < n) { // the tail of a short last block: never read past the end of the stream
-				const uint32_t *q = (const uint32_t*)pcm + base + (uint32_t)rel;
+				const uint32_t *q = src + base + (uint32_t)rel;
 				v.x = q[0];
 				if((uint32_t)rel + 1u < n) v.y = q[1];
 				if((uint32_t)rel + 2u < n) v.z = q[2];
 			}
 			raw[4 * j] = v.x; raw[4 * j + 1] = v.y; raw[4 * j + 2] = v.z; raw[4 * j + 3] = v.w;
 		}
-	}
+	};
+	if constexpr(PACKED16) { (void)xa; (void)xb; }
 	else {
 		const uint64_t end = base + n;
 #pragma unroll
@@ -650,6 +654,10 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? 5 : 4) fa_pack_fast_ker
 			int32_t xw[PF_W];
 			const uint32_t which = c.midside ? s.sig : (uint32_t)sc;
 			if constexpr(PACKED16) {
+				uint32_t raw[PF_W];
+				const uint32_t *src = (const uint32_t*)pcm;
+				if(sc == 1) asm volatile("" : "+s"(src));   // a fetch of its own, not the first subframe's values kept
+				fetch_packed(src, raw);
 				if(which == 0u) {
 #pragma unroll
 					for(int j = 0; j < PF_W; j++) xw[j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> s.wasted;
@@ -702,8 +710,8 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? 5 : 4) fa_pack_fast_ker
 					int32_t qc[HIST];
 #pragma unroll
 					for(int j = 0; j < HIST; j++) qc[j] = qsel[sc][j];
-					if(s.wide) lpc_each_dispatch<MAC_WIDE>(s.order, xw, qc, s.shift, keep);
-					else if(s.sbps <= 24) lpc_each_dispatch<MAC_I24>(s.order, xw, qc, s.shift, keep);
+					if(!NARROW && s.wide) lpc_each_dispatch<MAC_WIDE>(s.order, xw, qc, s.shift, keep);
+					else if(NARROW || s.sbps <= 24) lpc_each_dispatch<MAC_I24>(s.order, xw, qc, s.shift, keep);
 					else lpc_each_dispatch<MAC_I32>(s.order, xw, qc, s.shift, keep);
 				}
 				const uint32_t k = kk[sc];
@@ -1032,18 +1040,20 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 		const size_t lds = ((size_t)words * 4u + 15u) & ~(size_t)15u;
 		if(c->channels == 2) hipLaunchKernelGGL(fa_assign_kernel<2>, dim3(c->F), dim3(64), 0, st, *c, *w);
 		else hipLaunchKernelGGL(fa_assign_kernel<1>, dim3(c->F), dim3(64), 0, st, *c, *w);
-		if(c->channels == 2 && c->pcm_format == FLACAMD_PCM_S16) {
-			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((fa_pack_fast_kernel<2, true>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
-		}
-		else if(c->channels == 2) {
-			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((fa_pack_fast_kernel<2, false>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
-		}
-		else {
-			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((fa_pack_fast_kernel<1, false>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words);
-		}
+		// can any subframe take the 64-bit prediction sum (stream_encoder.c:3597-3603: bps + precision + ilog2(order) > 32)
+		// or carry more than 24-bit samples?
+		uint32_t lg = 0;
+		while((2u << lg) <= (c->max_lpc_order ? c->max_lpc_order : 1u)) lg++;
+		const uint32_t max_prec = c->prec_search ? FA_MAX_QLP_PRECISION : c->qlp_precision;
+		const uint32_t max_bps = c->bps + (c->midside ? 1u : 0u);
+		const bool narrow = max_bps <= 24u && max_bps + max_prec + lg <= 32u;
+#define PF_LAUNCH(...) do { \
+			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+			hipLaunchKernelGGL((fa_pack_fast_kernel<__VA_ARGS__>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words); } while(0)
+		if(c->channels == 2 && c->pcm_format == FLACAMD_PCM_S16) { if(narrow) PF_LAUNCH(2, true, true); else PF_LAUNCH(2, true, false); }
+		else if(c->channels == 2) PF_LAUNCH(2, false, false);
+		else PF_LAUNCH(1, false, false);
+#undef PF_LAUNCH
 		return;
 	}
 	fa_launch_pack_general(pcm, c, w, st, 0);
