@@ -548,11 +548,12 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 // PACKED16: 16-bit stereo input (FLACAMD_PCM_S16, NSUB == 2), fetched as one register per wide sample.
 // NARROW: no subframe of the stream can need the 64-bit prediction sum or samples beyond 24 bits (decided on the host).
 // The kernel is a chain of load, scan, emission, look-back, CRC and flush with barriers between, which more resident
-// workgroups hide.  With both (the 64-bit path is where the register count peaks: 105 against 89) it runs six
-// workgroups per CU with seven registers in scratch memory: 0.90 ms per hour of audio at four, 0.80 at five (nothing
-// spilled), 0.745 at six, 1.00 at eight (23 spilled).
+// workgroups hide.  With both (the 64-bit path is where the register count peaks) and the first subframe written out
+// before the second is looked at, it needs 79 registers: six workgroups per CU, nothing spilled.  Per hour of audio:
+// 0.90 ms at four workgroups per CU, 0.80 at five, 0.75 at six, 0.73 at seven (five registers in scratch memory, which
+// is 0.2 GB of traffic), 1.00 at eight.
 template<int NSUB, bool PACKED16, bool NARROW>
-__global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+__global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
@@ -599,8 +600,6 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 	// one register per wide sample) by each subframe in turn, which forms its signal in the same registers: the second
 	// fetch hits the cache, and holding the words across the first subframe's arithmetic instead costs the registers that
 	// decide whether five workgroups fit a CU
-	constexpr bool packed16 = PACKED16;
-	int32_t xa[PACKED16 ? 1 : PF_W], xb[PACKED16 ? 1 : PF_W];
 	auto fetch_packed = [&](const uint32_t *src, uint32_t (&raw)[PF_W]) {
 #pragma unroll
 		for(int j = 0; j < PF_W / 4; j++) {
@@ -616,8 +615,8 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 			raw[4 * j] = v.x; raw[4 * j + 1] = v.y; raw[4 * j + 2] = v.z; raw[4 * j + 3] = v.w;
 		}
 	};
-	if constexpr(PACKED16) { (void)xa; (void)xb; }
-	else {
+	// (other sample formats: both channels unpacked, likewise once per subframe)
+	auto fetch_wide = [&](const void *src, int32_t (&xa)[PF_W], int32_t (&xb)[PF_W]) {
 		const uint64_t end = base + n;
 #pragma unroll
 		for(int j = 0; j < PF_W / 4; j++) {
@@ -627,11 +626,11 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 #pragma unroll
 				for(int q = 0; q < 4; q++) { ta[q] = 0; tb[q] = 0; }
 			}
-			else pf_load4<NSUB>(pcm, c.pcm_format, base + (uint32_t)rel, end, ta, tb);
+			else pf_load4<NSUB>(src, c.pcm_format, base + (uint32_t)rel, end, ta, tb);
 #pragma unroll
 			for(int q = 0; q < 4; q++) { xa[4 * j + q] = ta[q]; xb[4 * j + q] = tb[q]; }
 		}
-	}
+	};
 
 	// ---- tokens of one subframe: folded residuals u[], the Rice parameter of this thread's
 	// partition, where a partition parameter precedes a token, and the bits of the run
@@ -676,6 +675,10 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 				}
 			}
 			else {
+			int32_t xa[PF_W], xb[PF_W];
+			const void *src = pcm;
+			if(sc == 1) asm volatile("" : "+s"(src));
+			fetch_wide(src, xa, xb);
 			if(which == 0u) {
 #pragma unroll
 				for(int j = 0; j < PF_W; j++) xw[j] = xa[j] >> s.wasted;
@@ -730,46 +733,72 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 		}
 		bits[sc] = mybits;
 	};
-	analyse(std::integral_constant<int, 0>{});
-	if constexpr(NSUB == 2) analyse(std::integral_constant<int, 1>{});
-
-	// ---- one scan for the whole frame
+	// ---- residual tokens of one subframe into the frame image
 	uint32_t ex[NSUB], tot[NSUB];
-	{
-		const uint32_t lane = tid & 63u, wv = tid >> 6;
-		uint32_t inc[NSUB];
-#pragma unroll
-		for(int sc = 0; sc < NSUB; sc++) inc[sc] = bits[sc];
-#pragma unroll
-		for(int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-			for(int sc = 0; sc < NSUB; sc++) { const uint32_t t = (uint32_t)__shfl_up((int)inc[sc], o, 64); if(lane >= (uint32_t)o) inc[sc] += t; }
-		}
-		if(lane == 63u) {
-#pragma unroll
-			for(int sc = 0; sc < NSUB; sc++) sh.wave_tot[wv][sc] = inc[sc];
-		}
-		__syncthreads();   // also orders the zeroing of bitbuf and the table load before their use
-#pragma unroll
-		for(int sc = 0; sc < NSUB; sc++) {
-			uint32_t pre = 0, all = 0;
-#pragma unroll
-			for(uint32_t i = 0; i < PF_THREADS / 64; i++) { const uint32_t t = sh.wave_tot[i][sc]; all += t; if(i < wv) pre += t; }
-			ex[sc] = pre + inc[sc] - bits[sc]; tot[sc] = all;
-		}
-	}
 	uint32_t start[NSUB];   // bit position of the head of each subframe
-	uint32_t total_bits = hf.nbytes * 8u;
+	auto emit = [&](auto sc_const) {
+		constexpr int sc = decltype(sc_const)::value;
+		const SubDesc &s = d[sc];
+		if(bits[sc] != 0) {
+			BitRun br; br.begin(bitbuf, start[sc] + s.head_bits + ex[sc]);
+			if(s.type == FA_SUB_VERBATIM) {
 #pragma unroll
-	for(int sc = 0; sc < NSUB; sc++) { start[sc] = total_bits; total_bits += d[sc].head_bits + tot[sc]; }
-	if(total_bits > cap_bits || __syncthreads_or(bad ? 1 : 0)) { // cannot happen for estimates that did not wrap; never write past the buffer
+				for(int q = 0; q < PF_CH; q++) if(i0 + (uint32_t)q < n) br.put(u[sc][q], s.sbps);
+			}
+			else {
+				const uint32_t k = kk[sc], plen = s.rice2 ? 5u : 4u;
+#pragma unroll
+				for(int q = 0; q < PF_CH; q++) {
+					const uint32_t i = i0 + (uint32_t)q;
+					if(i >= s.order && i < n) {
+						if(q == first_s[sc]) br.put(k, plen);
+						br.zeros(u[sc][q] >> k);                                          // unary part
+						br.put((1u << k) | (u[sc][q] & ((1u << k) - 1u)), k + 1u);       // stop bit + k low bits
+					}
+				}
+			}
+			br.end();
+		}
+	};
+	// exclusive scan of one subframe's bits per thread over the workgroup (one barrier; the first also orders the zeroing
+	// of bitbuf and the table load before their use)
+	auto scan = [&](auto sc_const) {
+		constexpr int sc = decltype(sc_const)::value;
+		const uint32_t lane = tid & 63u, wv = tid >> 6;
+		uint32_t inc = bits[sc];
+#pragma unroll
+		for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if(lane >= (uint32_t)o) inc += t; }
+		if(lane == 63u) sh.wave_tot[wv][sc] = inc;
+		__syncthreads();
+		uint32_t pre = 0, all = 0;
+#pragma unroll
+		for(uint32_t i = 0; i < PF_THREADS / 64; i++) { const uint32_t t = sh.wave_tot[i][sc]; all += t; if(i < wv) pre += t; }
+		ex[sc] = pre + inc - bits[sc]; tot[sc] = all;
+	};
+	// The first subframe's tokens are written before the second subframe is looked at (a scan each instead of one for
+	// both): its sixteen folded residuals per thread are gone from the registers by then
+	const bool emit_on = !(c.debug & 0x10u);
+	analyse(std::integral_constant<int, 0>{});
+	scan(std::integral_constant<int, 0>{});
+	start[0] = hf.nbytes * 8u;
+	uint32_t total_bits = start[0] + d[0].head_bits + tot[0];
+	bool over = total_bits > cap_bits;      // (the same for every thread)
+	if constexpr(NSUB == 2) {
+		if(!over && emit_on) emit(std::integral_constant<int, 0>{});
+		analyse(std::integral_constant<int, 1>{});
+		scan(std::integral_constant<int, 1>{});
+		start[1] = total_bits;
+		total_bits += d[1].head_bits + tot[1];
+		over = over || total_bits > cap_bits;
+	}
+	if(__syncthreads_or(bad ? 1 : 0) || over) { // cannot happen for estimates that did not wrap; never write past the buffer
 		if(tid == 0) {
 			atomicOr(w.status, 1u); w.frame_bytes[f] = 0;
 			if(c.direct_out) __hip_atomic_store(&w.lb[f], PF_LB_OWN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the frames behind this one must not wait for it
 		}
 		return;
 	}
-	// The frame's size is known before a bit of it is written: tell the frames behind (see the look-back below)
+	// The frame's size is known before the rest of it is written: tell the frames behind (see the look-back below)
 	const uint32_t frame_nb = ((total_bits + 7u) >> 3) + 2u;
 	if(c.direct_out && tid == 0)
 		__hip_atomic_store(&w.lb[f], (f == 0u ? PF_LB_ALL : PF_LB_OWN) | (unsigned long long)frame_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -819,34 +848,10 @@ __global__ void __launch_bounds__(PF_THREADS, (PACKED16 && NARROW) ? 6 : 4) fa_p
 		}
 	}
 
-	// ---- residual tokens
-	auto emit = [&](auto sc_const) {
-		constexpr int sc = decltype(sc_const)::value;
-		const SubDesc &s = d[sc];
-		if(bits[sc] != 0) {
-			BitRun br; br.begin(bitbuf, start[sc] + s.head_bits + ex[sc]);
-			if(s.type == FA_SUB_VERBATIM) {
-#pragma unroll
-				for(int q = 0; q < PF_CH; q++) if(i0 + (uint32_t)q < n) br.put(u[sc][q], s.sbps);
-			}
-			else {
-				const uint32_t k = kk[sc], plen = s.rice2 ? 5u : 4u;
-#pragma unroll
-				for(int q = 0; q < PF_CH; q++) {
-					const uint32_t i = i0 + (uint32_t)q;
-					if(i >= s.order && i < n) {
-						if(q == first_s[sc]) br.put(k, plen);
-						br.zeros(u[sc][q] >> k);                                          // unary part
-						br.put((1u << k) | (u[sc][q] & ((1u << k) - 1u)), k + 1u);       // stop bit + k low bits
-					}
-				}
-			}
-			br.end();
-		}
-	};
-	if(!(c.debug & 0x10u)) {
-		emit(std::integral_constant<int, 0>{});
+	// ---- residual tokens of the last subframe
+	if(emit_on) {
 		if constexpr(NSUB == 2) emit(std::integral_constant<int, 1>{});
+		else emit(std::integral_constant<int, 0>{});
 	}
 	__syncthreads();
 
