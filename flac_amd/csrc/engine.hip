@@ -261,14 +261,15 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 	}
 	{ const char *dbg = getenv("FLACAMD_DEBUG"); c.debug = dbg ? (uint32_t)strtoul(dbg, 0, 0) : 0u; }
 	c.spill = p.blocksize > FA_LDS_BLOCKSIZE ? 1u : 0u;
-	e->cand_group = c.max_cand < 24u ? c.max_cand : 24u;
+	// all candidates in one round where they are few; else sixteen at a time: with the signal that is 38 KB of LDS, four workgroups per CU
+	e->cand_group = c.max_cand <= 24u ? c.max_cand : 16u;
 	if(e->cand_group == 0) e->cand_group = 1;
 	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
 	// LDS of the general kernels: fewer candidates per pass, then the signal out of LDS, until a workgroup's tables fit
 	while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
 	if((fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u || fa_pack_lds_bytes(&c, 0) > 160u * 1024u) && !c.spill) {
 		c.spill = 1u;
-		e->cand_group = c.max_cand < 24u ? (c.max_cand ? c.max_cand : 1u) : 24u;
+		e->cand_group = c.max_cand <= 24u ? (c.max_cand ? c.max_cand : 1u) : 16u;
 		while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
 	}
 	if(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }

@@ -148,25 +148,43 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 	// lanes are in frame order, so if the first lane sits in the last frame all lanes do
 	const uint32_t f0 = (blockIdx.x * 64u) / c.nsig;
 	const uint32_t nloop = (!c.multi && f0 + 1 == c.F) ? c.last_n : c.N;   // short frames in between: their lanes add zeros past their end
+	const uint32_t ca = (s == 1u) ? 0u : 1u, cb = (s == 0u) ? 0u : (s == 3u ? 0xffffffffu : 1u), sh = (s == 2u) ? 1u : 0u;
 
 	for(uint32_t a = 0; a < c.num_apod; a++) {
 		const float *__restrict__ win = w.window + (size_t)a * c.N;
 		float acc[LAG], hist[LAG];
 #pragma unroll
 		for(int l = 0; l < LAG; l++) { acc[l] = 0.0f; hist[l] = 0.0f; }
-		int32_t nxt[4];
+		// GS samples per step, the next step's loads in flight while this one's sums are taken: a lane has nothing
+		// else to cover the latency of its loads with (every lane reads its own signal, few waves share a SIMD)
+		constexpr int GS = 16;
+		// no branch around a load: past the end the last sample is fetched again and replaced by zero
+		auto ld = [&](uint32_t i) {
+			const uint64_t wide = base + (i < n ? i : n - 1u);
+			int32_t v;
+			if(c.midside) {   // L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058) as (ca*l + cb*r) >> sh, 32-bit wrapping like fa_signal
+				int32_t l, r;
+				if(c.pcm_format == FLACAMD_PCM_S16) { const uint32_t lr = ((const uint32_t*)pcm)[wide]; l = (int16_t)(lr & 0xffffu); r = (int32_t)lr >> 16; }
+				else { const int2 lr = ((const int2*)pcm)[wide]; l = lr.x; r = lr.y; }
+				v = (int32_t)(ca * (uint32_t)l + cb * (uint32_t)r) >> sh;
+			}
+			else v = fa_pcm(pcm, c.pcm_format, c.channels, wide, s);
+			return i < n ? v : 0;
+		};
+		int32_t nxt[GS];
 #pragma unroll
-		for(int j = 0; j < 4; j++) nxt[j] = ((uint32_t)j < n) ? fa_signal(pcm, c, s, base + j) : 0;
-		for(uint32_t i0 = 0; i0 < nloop; i0 += 4) {
-			int32_t cur[4];
+		for(int j = 0; j < GS; j++) nxt[j] = ld((uint32_t)j);
+		for(uint32_t i0 = 0; i0 < nloop; i0 += GS) {
+			int32_t cur[GS];
 #pragma unroll
-			for(int j = 0; j < 4; j++) cur[j] = nxt[j];
+			for(int j = 0; j < GS; j++) cur[j] = nxt[j];
 #pragma unroll
-			for(int j = 0; j < 4; j++) { const uint32_t i = i0 + 4u + (uint32_t)j; nxt[j] = (i < n) ? fa_signal(pcm, c, s, base + i) : 0; }
+			for(int j = 0; j < GS; j++) nxt[j] = ld(i0 + (uint32_t)GS + (uint32_t)j);
 #pragma unroll
-			for(int j = 0; j < 4; j++) {
+			for(int j = 0; j < GS; j++) {
 				const uint32_t i = i0 + (uint32_t)j;
-				const float d = __fmul_rn((float)cur[j], win[i < c.N ? i : c.N - 1u]); // lpc.c:60
+				// lpc.c:60; past the end of the block the sample is zero and so is every product it enters
+				const float d = __fmul_rn((float)cur[j], win[i < c.N ? i : c.N - 1u]);
 #pragma unroll
 				for(int k = LAG - 1; k > 0; k--) hist[k] = hist[k-1];
 				hist[0] = d;

@@ -24,6 +24,7 @@
 // per LPC candidate.
 #include "engine_types.h"
 #include "residual.h"
+#include "wave_ops.h"
 
 // format.c:548-561
 __device__ __forceinline__ uint32_t limit_po(uint32_t limit, uint32_t blocksize, uint32_t order)
@@ -38,7 +39,7 @@ struct SearchShared {
 };
 
 template<typename SUM, bool SPILL>
-__global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
+__global__ void __launch_bounds__(256, 3) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
@@ -207,36 +208,54 @@ __global__ void __launch_bounds__(256) fa_search_kernel(const void *__restrict__
 			__syncthreads();
 		}
 
-		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition)
+		// ---- Rice parameter and bit estimate of every (candidate, partition order, partition).
+		// Item t = candidate * per + idx: idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
+		// so the items of one (candidate, order) are an aligned block of lanes: their estimates are added up inside the
+		// wave and one lane per block adds the total to the candidate's row.
 		const uint32_t per = 2u * parts0, per_log = maxpo_f + 1u;
-		for(uint32_t t = tid; t < ((c.debug & 2u) ? 0u : gn * per); t += 256) {
+		const uint32_t items = (c.debug & 2u) ? 0u : gn * per;
+		for(uint32_t t0 = 0; t0 < items; t0 += 256) {
+			const uint32_t t = t0 + tid;
 			const uint32_t ci = t >> per_log, idx = t & (per - 1u);
-			if(idx == per - 1u) continue;
-			// idx in [0, parts0) is order maxpo_f, the next parts0/2 entries order maxpo_f-1, ...
-			const uint32_t lvl = per_log - (32u - (uint32_t)__clz((int)(per - idx - 1u)));
-			const uint32_t off = per - (per >> lvl);
-			const uint32_t po = maxpo_f - lvl, p = idx - off;
-			const uint32_t info = cinfo[ci];
-			const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
-			if(po > maxpo_c || po < minpo_c) continue;
-			unsigned long long sum = psum[(size_t)ci * prow + idx];
-			if(((info >> 16) & 1u) && po == maxpo_c) sum &= 0xffffffffull;
-			const uint32_t nsamp = (n >> po) - (p == 0 ? order : 0u);
-			uint32_t k;
-			if(po == 0) k = FA_CAND_K(chdr[ci]);   // stream_encoder.c:3982-4029
-			else {                                  // :4052 smallest k with nsamp << k >= sum
-				k = 0;
-				if(sum > (unsigned long long)nsamp) {
-					const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)sum), bl_n = 32u - (uint32_t)__clz((int)nsamp);
-					k = bl_s - bl_n;
-					if(((unsigned long long)nsamp << k) < sum) k++;
+			uint32_t est = 0, lvl = 0, seg = 1;
+			bool on = false;
+			if(t < items && idx != per - 1u) {
+				lvl = per_log - (32u - (uint32_t)__clz((int)(per - idx - 1u)));
+				seg = per >> (lvl + 1u);
+				const uint32_t off = per - (per >> lvl);
+				const uint32_t po = maxpo_f - lvl, p = idx - off;
+				const uint32_t info = cinfo[ci];
+				const uint32_t order = info & 255u, maxpo_c = (info >> 8) & 15u, minpo_c = (info >> 12) & 15u;
+				if(po <= maxpo_c && po >= minpo_c) {
+					unsigned long long sum = psum[(size_t)ci * prow + idx];
+					if(((info >> 16) & 1u) && po == maxpo_c) sum &= 0xffffffffull;
+					const uint32_t nsamp = (n >> po) - (p == 0 ? order : 0u);
+					uint32_t k;
+					if(po == 0) k = FA_CAND_K(chdr[ci]);   // stream_encoder.c:3982-4029
+					else {                                  // :4052 smallest k with nsamp << k >= sum
+						k = 0;
+						if(sum > (unsigned long long)nsamp) {
+							const uint32_t bl_s = 64u - (uint32_t)__clzll((long long)sum), bl_n = 32u - (uint32_t)__clz((int)nsamp);
+							k = bl_s - bl_n;
+							if(((unsigned long long)nsamp << k) < sum) k++;
+						}
+						if(k >= c.k_limit) k = c.k_limit - 1u;
+					}
+					// :3929-3937, unsigned 32-bit arithmetic
+					est = 4u + (1u + k) * nsamp + (k ? (uint32_t)(sum >> (k - 1u)) : (uint32_t)(sum << 1)) - (nsamp >> 1);
+					kbuf[(size_t)ci * 2u * parts_cap + idx] = (uint8_t)k;
+					on = true;
 				}
-				if(k >= c.k_limit) k = c.k_limit - 1u;
 			}
-			// :3929-3937, unsigned 32-bit arithmetic
-			const uint32_t est = 4u + (1u + k) * nsamp + (k ? (uint32_t)(sum >> (k - 1u)) : (uint32_t)(sum << 1)) - (nsamp >> 1);
-			kbuf[(size_t)ci * 2u * parts_cap + idx] = (uint8_t)k;
-			atomicAdd(&lbits[ci * 16u + lvl], est);
+			uint32_t v = est, vn;
+			vn = block_sum_step<1>(v); v = seg >= 2u ? vn : v;
+			vn = block_sum_step<2>(v); v = seg >= 4u ? vn : v;
+			vn = block_sum_step<3>(v); v = seg >= 8u ? vn : v;
+			vn = block_sum_step<4>(v); v = seg >= 16u ? vn : v;
+			vn = block_sum_step<5>(v); v = seg >= 32u ? vn : v;
+			vn = block_sum_step<6>(v); v = seg >= 64u ? vn : v;
+			const uint32_t lead = (seg < 64u ? seg : 64u) - 1u;
+			if(on && (tid & lead) == 0) atomicAdd(&lbits[ci * 16u + lvl], v);
 		}
 		__syncthreads();
 
