@@ -199,11 +199,15 @@ struct flacamd_encoder {
 	uint32_t last_F, last_G;
 	int timing;
 	hipEvent_t ev[7];
+	hipEvent_t *cur_ev;                      // the stage events the batch being queued records: ev, or its row of qev
+	hipEvent_t qev[FLACAMD_QUEUE_DEPTH][7];  // made when the first batch is queued with timing on
+	int qev_made;
 	hipStream_t side; hipEvent_t ev_fork, ev_join;   // the autocorrelation stage runs beside the prep stage
 	float last_ms[6];
 	int have_timing;
 	// per-call tables of the multi-stream entry points: pinned host staging and a device buffer, both grow-only
 	void *h_tab; size_t h_tab_bytes; void *d_tab; size_t d_tab_bytes;
+	uint64_t *q_rec; uint32_t q_n; hipStream_t q_stream;   // queued batches: page-locked (status, total) pairs, how many are outstanding, their stream
 	hipStream_t md5s; hipEvent_t ev_tab, ev_md5;   // the clip batch hashes on a stream of its own beside the coding stages
 	const uint8_t *given_digests; void *given_ready;   // flacamd_encoder_use_digests: for the next clip batch only
 };
@@ -334,6 +338,7 @@ extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const f
 		if(he != hipSuccess) { rc = hip_fail(he, "hipMemcpy(window)"); hipFree(e->arena); free(e); return rc; }
 	}
 	for(int i = 0; i < 7; i++) (void)hipEventCreate(&e->ev[i]);
+	e->cur_ev = e->ev;
 	if(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess
 		|| hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { flacamd_encoder_destroy(e); return FLACAMD_E_DEVICE; }
 	*out = e;
@@ -345,7 +350,9 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 	if(!e) return;
 	hipSetDevice(e->device);
 	for(int i = 0; i < 7; i++) if(e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+	if(e->qev_made) for(uint32_t b = 0; b < FLACAMD_QUEUE_DEPTH; b++) for(int i = 0; i < 7; i++) (void)hipEventDestroy(e->qev[b][i]);
 	if(e->side) (void)hipStreamDestroy(e->side);
+	if(e->q_rec) (void)hipHostFree(e->q_rec);
 	if(e->ev_fork) (void)hipEventDestroy(e->ev_fork);
 	if(e->ev_join) (void)hipEventDestroy(e->ev_join);
 	if(e->arena) hipFree(e->arena);
@@ -370,6 +377,7 @@ extern "C" int flacamd_encoder_last_timing(flacamd_encoder *e, float ms[6])
 }
 
 static int run_batch(flacamd_encoder *e, const FaCfg &c, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, hipStream_t st);
+static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pcm, void *d_out, size_t out_cap, uint32_t *d_frame_bytes, hipStream_t st);
 
 extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
@@ -393,6 +401,76 @@ extern "C" int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int 
 	c.first_frame = first_frame_number; c.prev_assignment = prev_assignment;
 	c.multi = 0; c.skip_full = 0;
 	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
+}
+
+// The same batch queued behind whatever the stream holds, nothing waited for: the host runs ahead of the device and
+// the next batch's first kernel follows this batch's last without the round trip of a synchronisation in between.
+// Status word and total go to a page-locked record per outstanding batch; flacamd_encoder_wait reads them.
+extern "C" int flacamd_encode_device_queue(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, void *stream)
+{
+	if(!e || !d_pcm || !d_out || nsamples == 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(pcm_format == FLACAMD_PCM_S16 && e->p.bits_per_sample > 16) return FLACAMD_E_INVALID_ARGUMENT;
+	const uint32_t N = e->cfg.N;
+	const uint64_t F64 = (nsamples + N - 1) / N;
+	if(!final_block && nsamples % N != 0) return FLACAMD_E_INVALID_ARGUMENT;
+	if(F64 > e->max_frames) return FLACAMD_E_CAPACITY;
+	hipStream_t st = (hipStream_t)stream;
+	if(e->q_n >= FLACAMD_QUEUE_DEPTH) return FLACAMD_E_CAPACITY;
+	if(e->q_n > 0 && st != e->q_stream) return FLACAMD_E_INVALID_ARGUMENT;   // the batches share the work arrays: one stream orders them
+	HIP_TRY(hipSetDevice(e->device));
+	if(!e->q_rec) HIP_TRY(hipHostMalloc((void**)&e->q_rec, sizeof(uint64_t) * 2u * FLACAMD_QUEUE_DEPTH, hipHostMallocDefault));
+
+	FaCfg c = e->cfg;
+	c.pcm_format = (uint32_t)pcm_format;
+	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
+	c.last_n = (uint32_t)(nsamples - (F64 - 1) * N);
+	c.last_fractional = (final_block && c.last_n != N) ? 1u : 0u;
+	c.first_frame = first_frame_number; c.prev_assignment = prev_assignment;
+	c.multi = 0; c.skip_full = 0;
+	if(e->timing && !e->qev_made) {
+		for(uint32_t b = 0; b < FLACAMD_QUEUE_DEPTH; b++) for(int i = 0; i < 7; i++) HIP_TRY(hipEventCreate(&e->qev[b][i]));
+		e->qev_made = 1;
+	}
+	if(e->timing) e->cur_ev = e->qev[e->q_n];
+	const int rc = enqueue_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, st);
+	e->cur_ev = e->ev;
+	if(rc != FLACAMD_OK) return rc;
+	uint64_t *rec = e->q_rec + 2u * e->q_n;
+	rec[0] = 0;
+	HIP_TRY(hipMemcpyAsync(&rec[0], e->work.status, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&rec[1], e->work.offsets + c.F, 8, hipMemcpyDeviceToHost, st));
+	e->q_stream = st; e->q_n++;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encoder_wait(flacamd_encoder *e, uint64_t *h_total_bytes, uint32_t max_totals, uint32_t *n_batches)
+{
+	if(!e) return FLACAMD_E_INVALID_ARGUMENT;
+	if(n_batches) *n_batches = e->q_n;
+	if(e->q_n == 0) return FLACAMD_OK;
+	HIP_TRY(hipSetDevice(e->device));
+	const uint32_t n = e->q_n;
+	e->q_n = 0;
+	HIP_TRY(hipStreamSynchronize(e->q_stream));
+	if(e->timing && e->qev_made) {   // stage times: the mean over the batches waited for
+		for(int i = 0; i < 6; i++) {
+			float sum = 0.0f, ms = 0.0f;
+			for(uint32_t b = 0; b < n; b++) { if(hipEventElapsedTime(&ms, e->qev[b][i], e->qev[b][i+1]) == hipSuccess) sum += ms; }
+			e->last_ms[i] = sum / (float)n;
+		}
+		e->have_timing = 1;
+	}
+	int rc = FLACAMD_OK;
+	for(uint32_t i = 0; i < n; i++) {
+		const uint32_t status = (uint32_t)e->q_rec[2u * i];
+		if(h_total_bytes && i < max_totals) h_total_bytes[i] = e->q_rec[2u * i + 1u];
+		if(rc == FLACAMD_OK && (status & 1u)) rc = FLACAMD_E_FRAME_OVERFLOW;
+		if(rc == FLACAMD_OK && (status & 2u)) rc = FLACAMD_E_CAPACITY;
+	}
+	return rc;
 }
 
 // A frame did not fit its slot.  Slots are sized for a verbatim frame with slack, and the encoder only keeps a subframe
@@ -429,26 +507,31 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 
 	HIP_TRY(hipMemsetAsync(e->work.status, 0, 4, st));
 	const bool tm = e->timing != 0;
-	if(tm) (void)hipEventRecord(e->ev[0], st);
+	if(tm) (void)hipEventRecord(e->cur_ev[0], st);
 	// prep and autocorrelation read the same PCM and do not depend on each other (the model stage
 	// rescales the sums by the wasted bits): side by side on two streams, joined before the model
 	const bool fork = c.max_lpc_order > 0 && !(c.debug & 0x10000u);
 	// the fixed predictors' partition sums are a by-product of the preparation kernel's difference pass: the search kernel need not redo it
 	c.fixed_psum = (e->work.fixed_psum && fa_prep_fast_ok(d_pcm, &c) && fa_search_fast_ok(d_pcm, &c) && !(c.debug & 0x40000u)) ? 1u : 0u;
+	// The autocorrelation kernel is the longer of the two and goes on the caller's stream: it starts the moment the
+	// batch before it ends, while whatever goes to the side stream first waits for the fork event to cross queues
+	// (0.3 ms late when batches are queued back to back)
+	const bool swap = fork && !(c.debug & 0x400000u);
 	if(fork) {
 		HIP_TRY(hipEventRecord(e->ev_fork, st));
 		HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-		fa_launch_autoc(d_pcm, &c, &e->work, e->side);
+		fa_launch_autoc(d_pcm, &c, &e->work, swap ? st : e->side);
 	}
 	// (a short last block has a preparation kernel of its own: behind the autocorrelation kernel, which ends first)
-	fa_launch_prep(d_pcm, &c, &e->work, st, fork ? e->side : st);
+	if(swap) fa_launch_prep(d_pcm, &c, &e->work, e->side, e->side);
+	else fa_launch_prep(d_pcm, &c, &e->work, st, fork ? e->side : st);
 	if(fork) HIP_TRY(hipEventRecord(e->ev_join, e->side));
-	if(tm) (void)hipEventRecord(e->ev[1], st);
+	if(tm) (void)hipEventRecord(e->cur_ev[1], st);
 	if(fork) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
 	else if(c.max_lpc_order > 0) fa_launch_autoc(d_pcm, &c, &e->work, st);
-	if(tm) (void)hipEventRecord(e->ev[2], st);
+	if(tm) (void)hipEventRecord(e->cur_ev[2], st);
 	fa_launch_model(&c, &e->work, st);
-	if(tm) hipEventRecord(e->ev[3], st);
+	if(tm) hipEventRecord(e->cur_ev[3], st);
 	if(fa_search_rest_frames(d_pcm, &c) && !(c.debug & 0x10000u)) {
 		// the short last frame's search beside the others' (it is a handful of workgroups with the chip to themselves otherwise)
 		HIP_TRY(hipEventRecord(e->ev_fork, st));
@@ -458,17 +541,17 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 		HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
 	}
 	else fa_launch_search(d_pcm, &c, &e->work, e->cand_group, e->sum64, st);
-	if(tm) hipEventRecord(e->ev[4], st);
+	if(tm) hipEventRecord(e->cur_ev[4], st);
 	// frames straight into the caller's buffer where the register-resident pack kernel takes the batch; else into slots and a copy
 	c.direct_out = (fa_pack_direct_ok(d_pcm, &c) && !(c.debug & 3u)) ? 1u : 0u;
 	FaWork ww = e->work;
 	ww.out = (uint8_t*)d_out; ww.out_cap = out_cap; ww.frame_bytes_out = d_frame_bytes;
 	if(c.direct_out) HIP_TRY(hipMemsetAsync(ww.lb, 0, (size_t)c.F * 8u, st));
 	if(!(c.debug & 3u)) fa_launch_pack(d_pcm, &c, &ww, st);
-	if(tm) hipEventRecord(e->ev[5], st);
+	if(tm) hipEventRecord(e->cur_ev[5], st);
 	if(c.direct_out) fa_launch_offsets(&c, &ww, st);
 	else fa_launch_gather(&c, &e->work, d_out, out_cap, d_frame_bytes, st);
-	if(tm) hipEventRecord(e->ev[6], st);
+	if(tm) hipEventRecord(e->cur_ev[6], st);
 	HIP_TRY(hipGetLastError());
 	return FLACAMD_OK;
 }

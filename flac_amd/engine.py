@@ -88,6 +88,8 @@ def lib():
         L.flacamd_encoder_max_output_bytes.argtypes = [vp, u32]
         L.flacamd_encoder_max_output_bytes.restype = sz
         L.flacamd_encode_device.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), vp]
+        L.flacamd_encode_device_queue.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, vp]
+        L.flacamd_encoder_wait.argtypes = [vp, C.POINTER(u64), u32, C.POINTER(u32)]
         L.flacamd_encode_streams_device.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp, sz, vp, C.POINTER(u64), vp]
         L.flacamd_encode_clips_device.argtypes = [vp, vp, C.c_int, u32, vp, vp, vp, sz, vp, C.POINTER(u64), vp]
         L.flacamd_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), C.POINTER(u32)]
@@ -191,9 +193,9 @@ class Encoder:
     def last_timing(self):
         ms = (C.c_float * 6)()
         _check(self._lib.flacamd_encoder_last_timing(self._h, C.byref(ms)), "flacamd_encoder_last_timing")
-        # prep and the autocorrelation run side by side on two streams: the first interval ends when prep does, the
-        # second is what was left of the autocorrelation to wait for at the join
-        return dict(zip(("prep_beside_autoc", "autoc_join_wait", "model", "search", "pack", "gather"), [float(v) for v in ms]))
+        # the autocorrelation and prep run side by side on two streams: the first interval ends when the autocorrelation
+        # (on the caller's stream) does, the second is what was left of prep to wait for at the join
+        return dict(zip(("autoc_beside_prep", "prep_join_wait", "model", "search", "pack", "gather"), [float(v) for v in ms]))
 
     def encode_host(self, pcm, final=True, first_frame=0, prev_assignment=0):
         """pcm: numpy (samples, channels) int32 or int16. Returns (list of frame bytes, last assignment)."""
@@ -235,6 +237,19 @@ class Encoder:
         _check(self._lib.flacamd_encode_device(self._h, d_pcm_ptr, fmt, nsamples, 1 if final else 0, first_frame, prev_assignment,
                                                 d_out_ptr, out_cap, d_frame_bytes_ptr, C.byref(total), stream), "flacamd_encode_device")
         return int(total.value)
+
+    def encode_device_queue(self, d_pcm_ptr, fmt, nsamples, d_out_ptr, out_cap, d_frame_bytes_ptr, final=True, first_frame=0,
+                            prev_assignment=0, stream=None):
+        """flacamd_encode_device_queue: the batch is queued, nothing is waited for; wait() collects."""
+        _check(self._lib.flacamd_encode_device_queue(self._h, d_pcm_ptr, fmt, nsamples, 1 if final else 0, first_frame, prev_assignment,
+                                                      d_out_ptr, out_cap, d_frame_bytes_ptr, stream), "flacamd_encode_device_queue")
+
+    def wait(self):
+        """flacamd_encoder_wait: total bytes of every queued batch, in queue order."""
+        totals = (C.c_uint64 * 16)()
+        n = C.c_uint32(0)
+        _check(self._lib.flacamd_encoder_wait(self._h, totals, 16, C.byref(n)), "flacamd_encoder_wait")
+        return [int(totals[i]) for i in range(n.value)]
 
     def encode_streams_device(self, d_pcm_ptr, fmt, starts, lengths, d_out_ptr, out_cap, d_frame_bytes_ptr, stream=None):
         """Several complete streams in one pass (flacamd_encode_streams_device): starts / lengths in wide samples,

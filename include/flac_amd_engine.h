@@ -128,6 +128,22 @@ int flacamd_encode_device(flacamd_encoder *e, const void *d_pcm, int pcm_format,
 	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
 	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, uint64_t *h_total_bytes, void *stream);
 
+/* flacamd_encode_device without its synchronisation: the batch is queued on `stream` and the call returns while the
+ * device works, so a caller that codes batch after batch (process_frame_ in a loop, stream_encoder.c:2866-2923) keeps
+ * the device busy across batch borders.  Up to FLACAMD_QUEUE_DEPTH batches of one encoder may be outstanding, all on
+ * the same stream (they share the encoder's work arrays and run in order); each needs its own d_out / d_frame_bytes
+ * until it has been waited for.  A loose mid/side stream's batches must be whole decision periods (prev_assignment
+ * of a queued batch cannot come from one still running).
+ * flacamd_encoder_wait waits for every outstanding batch, stores their total sizes in h_total_bytes[0..] (in queue
+ * order, at most max_totals) and their number in *n_batches (either may be NULL), and returns the first failure among
+ * them: FLACAMD_E_FRAME_OVERFLOW (a frame beyond the verbatim bound: code that batch again with flacamd_encode_device,
+ * which runs the second pass) or FLACAMD_E_CAPACITY (that total is the size its output buffer needs). */
+#define FLACAMD_QUEUE_DEPTH 16u
+int flacamd_encode_device_queue(flacamd_encoder *e, const void *d_pcm, int pcm_format, uint64_t nsamples,
+	int final_block, uint32_t first_frame_number, uint32_t prev_assignment,
+	void *d_out, size_t out_cap, uint32_t *d_frame_bytes, void *stream);
+int flacamd_encoder_wait(flacamd_encoder *e, uint64_t *h_total_bytes, uint32_t max_totals, uint32_t *n_batches);
+
 /* Several complete, independent streams of the encoder's format in ONE pass over the device (many short
  * clips: one call instead of one per clip).  Stream i is h_len[i] wide samples starting at wide sample
  * h_start[i] of d_pcm; the streams tile the buffer in whole blocks: h_start[0] = 0 and h_start[i + 1] =

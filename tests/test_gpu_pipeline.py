@@ -119,3 +119,56 @@ def test_encoder_after_encoder_starts_from_a_clean_pipe(gpu_engine):
         assert b.process_interleaved(pcm) and b.finish()
         assert b.streaminfo["md5sum"] == hashlib.md5(pcm.astype("<i2").tobytes()).digest(), nbatches_before
         b.close()
+
+
+def test_queued_batches_equal_the_synchronous_call(gpu_engine):
+    """flacamd_encode_device_queue: several batches of one stream queued back to back (nothing waited for in between),
+    each into its own output, give the frames the synchronous entry point gives and the oracle's; a batch whose output
+    buffer is too small is reported by the wait call; more than FLACAMD_QUEUE_DEPTH outstanding batches are refused."""
+    import torch
+    pcm = synth.music_like(9.0, seed=31).astype(np.int16)[: 4096 * 70 + 1234]
+    fp, _ = ob.make_params(2, 16, 44100, level=8)
+    want = ob.oracle_encode(fp, pcm.astype(np.int32))["frames"]
+    p = gpu_engine.make_params(2, 16, 44100, level=8)
+    per = 24                                   # frames per batch: 24, 24, 23 (the last with the short block)
+    nframes = (len(pcm) + 4095) // 4096
+    enc = gpu_engine.Encoder(p, max_frames=per)
+    enc.set_timing(True)
+    d = torch.from_numpy(pcm).cuda()
+    cap = enc.max_output_bytes(per)
+    outs, fbs, spans = [], [], []
+    for f0 in range(0, nframes, per):
+        f1 = min(f0 + per, nframes)
+        ns = min(len(pcm), f1 * 4096) - f0 * 4096
+        outs.append(torch.empty(cap, dtype=torch.uint8, device="cuda"))
+        fbs.append(torch.zeros(per, dtype=torch.int32, device="cuda"))
+        spans.append((f0, f1, ns))
+        enc.encode_device_queue(d.data_ptr() + f0 * 4096 * 4, gpu_engine.PCM_S16, ns, outs[-1].data_ptr(), cap, fbs[-1].data_ptr(),
+                                final=(f1 == nframes), first_frame=f0)
+    totals = enc.wait()
+    assert len(totals) == len(spans)
+    assert all(v > 0 for v in enc.last_timing().values())
+    got = []
+    for (f0, f1, ns), out, fb, total in zip(spans, outs, fbs, totals):
+        sizes = fb[: f1 - f0].cpu().numpy()
+        assert int(sizes.sum()) == total
+        got += _split(out[:total].cpu().numpy().tobytes(), sizes)
+        # the synchronous call on the same batch
+        out2 = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        fb2 = torch.zeros(per, dtype=torch.int32, device="cuda")
+        t2 = enc.encode_device(d.data_ptr() + f0 * 4096 * 4, gpu_engine.PCM_S16, ns, out2.data_ptr(), cap, fb2.data_ptr(), final=(f1 == nframes), first_frame=f0)
+        assert t2 == total and torch.equal(out2[:total], out[:total]) and torch.equal(fb2, fb)
+    assert got == want
+    assert enc.wait() == []                    # nothing outstanding
+    # too small an output buffer: reported when waited for, with the size it takes
+    small = torch.empty(1000, dtype=torch.uint8, device="cuda")
+    enc.encode_device_queue(d.data_ptr(), gpu_engine.PCM_S16, per * 4096, small.data_ptr(), 1000, fbs[0].data_ptr(), final=False)
+    with pytest.raises(gpu_engine.EngineError):
+        enc.wait()
+    # the queue is bounded
+    for _ in range(16):
+        enc.encode_device_queue(d.data_ptr(), gpu_engine.PCM_S16, per * 4096, outs[0].data_ptr(), cap, fbs[0].data_ptr(), final=False)
+    with pytest.raises(gpu_engine.EngineError):
+        enc.encode_device_queue(d.data_ptr(), gpu_engine.PCM_S16, per * 4096, outs[0].data_ptr(), cap, fbs[0].data_ptr(), final=False)
+    assert len(enc.wait()) == 16
+    enc.close()
