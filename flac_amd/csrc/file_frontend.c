@@ -244,6 +244,62 @@ static void seek_template(const char *spec, FLAC__uint64 total, unsigned rate, p
 }
 
 /* ---- encode ---- */
+/* --skip / --until values: "123456" (samples) or "mm:ss.sss", --until also "+..." (after the skip point) and "-..." (before the
+ * end): flac__utils_parse_skip_until_specification and flac__utils_canonicalize_skip_until_specification (src/flac/utils.c:36-76, :170-219) */
+typedef struct { int is_relative, value_is_samples; int64_t samples; double seconds; } range_spec;
+
+static int parse_range_spec(const char *s, range_spec *sp)
+{
+	int negative = 0; const char *p; uint64_t v = 0; int all_digits;
+	sp->is_relative = 0; sp->value_is_samples = 1; sp->samples = 0; sp->seconds = 0.0;
+	if(!s) return 1;
+	if(*s == '-') { negative = 1; sp->is_relative = 1; s++; }
+	else if(*s == '+') { sp->is_relative = 1; s++; }
+	all_digits = *s != 0;
+	for(p = s; *p; p++) { if(*p < '0' || *p > '9') { all_digits = 0; break; } v = v * 10 + (uint64_t)(*p - '0'); }
+	if(all_digits) sp->samples = negative ? -(int64_t)v : (int64_t)v;
+	else { /* [0-9]+:[0-9]*[.,]?[0-9]* */
+		unsigned minutes; char *end; double sec;
+		if(*s < '0' || *s > '9') return 0;
+		minutes = (unsigned)(*s++ - '0');
+		while(*s != ':') { if(*s < '0' || *s > '9') return 0; minutes = minutes * 10 + (unsigned)(*s++ - '0'); }
+		s++;
+		if(strspn(s, "1234567890.,") != strlen(s)) return 0;
+		sec = strtod(s, &end);
+		if(end == s || *end) return 0;
+		sp->value_is_samples = 0; sp->seconds = (double)minutes * 60. + sec;
+		if(negative) sp->seconds = -sp->seconds;
+	}
+	return 1;
+}
+
+static void canonicalize_range_spec(range_spec *sp, unsigned sample_rate)
+{
+	if(!sp->value_is_samples) { sp->samples = (int64_t)(sp->seconds * (double)sample_rate); sp->value_is_samples = 1; }
+}
+
+/* canonicalize_until_specification (src/flac/encode.c:2246-2289, src/flac/decode.c:498-541): 0 = to the end */
+static int canonicalize_until(range_spec *sp, unsigned sample_rate, uint64_t skip, uint64_t total_in, flacamd_file_result *res)
+{
+	canonicalize_range_spec(sp, sample_rate);
+	if(sp->is_relative && sp->samples == 0) { sp->is_relative = 0; return 0; }
+	if(total_in == 0) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "cannot use --until when input length is unknown");
+	if(sp->is_relative) { if(sp->samples <= 0) sp->samples += (int64_t)total_in; else sp->samples += (int64_t)skip; sp->is_relative = 0; }
+	if(sp->samples < 0) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "--until value is before beginning of input");
+	if((uint64_t)sp->samples <= skip) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "--until value is before --skip point");
+	if((uint64_t)sp->samples > total_in) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "--until value is after end of input");
+	return 0;
+}
+
+/* the two option strings as the tool's main() takes them (src/flac/main.c:1842-1853): --skip absolute, --until defaults to "-0" */
+static int parse_range_options(const char *skip, const char *until, range_spec *sk, range_spec *un, flacamd_file_result *res)
+{
+	if(!parse_range_spec(skip, sk) || sk->is_relative) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid value for --skip");
+	if(!parse_range_spec(until, un)) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid value for --until");
+	if(!until) un->is_relative = 1;
+	return 0;
+}
+
 int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd_file_options *opt, flacamd_file_result *res)
 {
 	flacamd_file_options defaults;
@@ -301,6 +357,20 @@ int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd
 	bytes_per_wide = format == FLACAMD_FILE_RAW ? (uint64_t)in.channels * ((in.bps + 7) / 8) : (uint64_t)in.channels * (in.bps / 8);
 	if(bytes_per_wide == 0 || (in.bps != 8 && in.bps != 16 && in.bps != 24)) { rc = fail(res, FLACAMD_E_UNSUPPORTED, "unsupported container width %u", in.bps); goto done; }
 	total = in.data_bytes / bytes_per_wide;   /* total_samples_to_encode: what the header promises (E:1079) */
+	{ /* --skip / --until: the sample range [skip, until) of the input (E:1091-1150) */
+		range_spec sk, un; uint64_t skip, until, cut;
+		if((rc = parse_range_options(opt->skip, opt->until, &sk, &un, res)) != 0) goto done;
+		canonicalize_range_spec(&sk, in.sample_rate);
+		skip = (uint64_t)sk.samples;
+		if((rc = canonicalize_until(&un, in.sample_rate, skip, total, res)) != 0) goto done;
+		until = (uint64_t)un.samples;
+		if(skip > total) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "during read while skipping samples"); goto done; }
+		if(until > 0) { in.data_bytes -= (total - until) * bytes_per_wide; total = until; }
+		cut = skip * bytes_per_wide;
+		in.data += cut; in.data_bytes -= cut; total -= skip;
+		in.available_bytes = in.available_bytes > cut ? in.available_bytes - cut : 0;
+		if(in.available_bytes > in.data_bytes) in.available_bytes = in.data_bytes;
+	}
 
 	/* metadata in the tool's order: seek table, tags, padding (E:2016-2053) */
 	{
@@ -408,6 +478,8 @@ typedef struct {
 	FILE *out; int format; flacamd_file_result *res;
 	unsigned channels, bps, sample_rate; FLAC__uint64 total_samples, written_samples; uint32_t channel_mask;
 	int got_streaminfo, header_written, failed;
+	FLAC__uint64 skip, until;   /* the range asked for, until 0 = to the end */
+	int stopped_at_until;
 	uint8_t *bytes; size_t bytes_cap;
 } decode_session;
 
@@ -478,12 +550,17 @@ static void dec_error(const FLAC__StreamDecoder *d, FLAC__StreamDecoderErrorStat
 static FLAC__StreamDecoderWriteStatus dec_write(const FLAC__StreamDecoder *d, const FLAC__Frame *fr, const FLAC__int32 * const buffer[], void *cd)
 {
 	decode_session *s = (decode_session*)cd;
-	const unsigned bps = fr->header.bits_per_sample, ch = fr->header.channels, n = fr->header.blocksize;
+	const unsigned bps = fr->header.bits_per_sample, ch = fr->header.channels; unsigned n = fr->header.blocksize;
 	const unsigned shift = (s->format != FLACAMD_FILE_RAW && (bps % 8)) ? 8 - (bps % 8) : 0, width = (bps + shift + 7) / 8;
 	const int big = s->format == FLACAMD_FILE_AIFF, uns = s->format == FLACAMD_FILE_WAVE && bps <= 8;
 	const int32_t bias = uns ? (int32_t)1 << (bps + shift - 1) : 0;
 	unsigned i, c; uint8_t *p; size_t need;
 	(void)d;
+	if(s->until > 0) { /* D:1069-1081: nothing past the --until point, and decoding ends there */
+		const FLAC__uint64 passed = s->skip + s->written_samples;
+		if(passed + n > s->until) n = (unsigned)(s->until - passed);
+		if(n == 0) { s->stopped_at_until = 1; return FLAC__STREAM_DECODER_WRITE_STATUS_ABORT; }
+	}
 	if(!s->header_written) {
 		if(!s->got_streaminfo) { s->channels = ch; s->bps = bps; s->sample_rate = fr->header.sample_rate; }
 		if(s->channel_mask == 0) { static const uint32_t dflt[7] = { 0, 0x0001, 0x0003, 0x0007, 0x0033, 0x0607, 0x060f }; if(s->channels <= 6) s->channel_mask = dflt[s->channels]; } /* D:355-382 */
@@ -506,10 +583,17 @@ static FLAC__StreamDecoderWriteStatus dec_write(const FLAC__StreamDecoder *d, co
 
 int flacamd_decode_file(const char *in_path, const char *out_path, int output_format, int device, flacamd_file_result *res)
 {
+	return flacamd_decode_file_range(in_path, out_path, output_format, device, 0, 0, res);
+}
+
+int flacamd_decode_file_range(const char *in_path, const char *out_path, int output_format, int device, const char *skip, const char *until, flacamd_file_result *res)
+{
 	decode_session s; FLAC__StreamDecoder *dec; int rc = 0; FLAC__bool ok, md5_ok;
+	range_spec sk, un;
 	if(res) memset(res, 0, sizeof *res);
 	if(!in_path || !out_path) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "missing path");
 	if(output_format != FLACAMD_FILE_WAVE && output_format != FLACAMD_FILE_AIFF && output_format != FLACAMD_FILE_RAW) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "unknown output format %d", output_format);
+	if((rc = parse_range_options(skip, until, &sk, &un, res)) != 0) return rc;
 	memset(&s, 0, sizeof s);
 	s.format = output_format; s.res = res;
 	s.out = fopen(out_path, "wb");
@@ -524,9 +608,26 @@ int flacamd_decode_file(const char *in_path, const char *out_path, int output_fo
 		rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "initializing decoder for %s: %s", in_path, FLAC__stream_decoder_get_resolved_state_string(dec));
 		FLAC__stream_decoder_delete(dec); fclose(s.out); return rc;
 	}
-	ok = FLAC__stream_decoder_process_until_end_of_stream(dec);
-	if(!ok || s.failed) rc = fail(res, FLACAMD_E_BAD_STREAM, "while decoding: %s", FLAC__stream_decoder_get_resolved_state_string(dec));
-	md5_ok = FLAC__stream_decoder_finish(dec);
+	ok = FLAC__stream_decoder_process_until_end_of_metadata(dec);
+	if(ok && !s.failed && (skip || until)) { /* the range against STREAMINFO (D:1272-1309), then to the skip point (D:392-399) */
+		const FLAC__uint64 total = s.got_streaminfo ? s.total_samples : 0;
+		canonicalize_range_spec(&sk, s.sample_rate);
+		s.skip = (FLAC__uint64)sk.samples;
+		if(total > 0 && s.skip >= total) rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "trying to --skip more samples than in stream");
+		else if(total == 0 && s.skip > 0) rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "can't --skip when FLAC metadata has total sample count of 0");
+		else rc = canonicalize_until(&un, s.sample_rate, s.skip, total, res);
+		if(!rc) {
+			s.until = (FLAC__uint64)un.samples;
+			s.total_samples = total - s.skip;
+			if(s.until > 0) s.total_samples -= total - s.until;
+			if(s.skip > 0 && !FLAC__stream_decoder_seek_absolute(dec, s.skip)) rc = fail(res, FLACAMD_E_BAD_STREAM, "seeking while skipping bytes: %s", FLAC__stream_decoder_get_resolved_state_string(dec));
+		}
+	}
+	if(!rc) {
+		if(ok) ok = FLAC__stream_decoder_process_until_end_of_stream(dec);
+		if((!ok && !s.stopped_at_until) || s.failed) rc = fail(res, FLACAMD_E_BAD_STREAM, "while decoding: %s", FLAC__stream_decoder_get_resolved_state_string(dec));
+	}
+	md5_ok = FLAC__stream_decoder_finish(dec) || s.stopped_at_until;   /* D:448 */
 	FLAC__stream_decoder_delete(dec);
 	if(!rc && !s.header_written && s.got_streaminfo && s.format != FLACAMD_FILE_RAW) { if(write_header(&s, s.out, 0) != 0) rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "writing the header"); s.header_written = 1; } /* a stream without frames */
 	if(!rc && s.format != FLACAMD_FILE_RAW) {

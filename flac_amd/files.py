@@ -12,7 +12,7 @@ class FileOptions(C.Structure):
     _fields_ = [("compression_level", C.c_uint), ("verify", C.c_int), ("lax", C.c_int), ("padding", C.c_int), ("seekpoints", C.c_char_p),
                 ("tags", C.POINTER(C.c_char_p)), ("num_tags", C.c_uint), ("blocksize", C.c_uint), ("input_format", C.c_int),
                 ("raw_channels", C.c_uint), ("raw_bps", C.c_uint), ("raw_sample_rate", C.c_uint), ("raw_big_endian", C.c_int), ("raw_unsigned", C.c_int),
-                ("device", C.c_int), ("batch_frames", C.c_uint)]
+                ("device", C.c_int), ("batch_frames", C.c_uint), ("skip", C.c_char_p), ("until", C.c_char_p)]
 
 
 class FileResult(C.Structure):
@@ -37,6 +37,7 @@ def _lib():
         L.flacamd_file_options_init.restype = None
         L.flacamd_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(FileOptions), C.POINTER(FileResult)]
         L.flacamd_decode_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(FileResult)]
+        L.flacamd_decode_file_range.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(FileResult)]
         _bound = True
     return L
 
@@ -49,7 +50,7 @@ def _result(rc, res):
 
 
 def encode_file(in_path, out_path, level=5, verify=False, lax=False, padding=-1, seekpoints=None, tags=(), blocksize=0,
-                input_format=AUTO, raw=None, device=0, batch_frames=0):
+                input_format=AUTO, raw=None, device=0, batch_frames=0, skip=None, until=None):
     """raw: dict(channels=, bps=, sample_rate=, big_endian=False, unsigned=False) with input_format=RAW.
     seekpoints: None for the tool's default, "" for none, else ';'-terminated -S values ("10s;", "X;", "4x;", "1234;")."""
     L = _lib()
@@ -61,6 +62,8 @@ def encode_file(in_path, out_path, level=5, verify=False, lax=False, padding=-1,
     arr = (C.c_char_p * max(1, len(enc)))(*enc)
     o.tags, o.num_tags = C.cast(arr, C.POINTER(C.c_char_p)), len(enc)
     o.input_format, o.device, o.batch_frames = input_format, device, batch_frames
+    o.skip = None if skip is None else str(skip).encode()      # --skip / --until as the tool takes them
+    o.until = None if until is None else str(until).encode()
     if raw:
         o.raw_channels, o.raw_bps, o.raw_sample_rate = raw["channels"], raw["bps"], raw["sample_rate"]
         o.raw_big_endian, o.raw_unsigned = int(raw.get("big_endian", False)), int(raw.get("unsigned", False))
@@ -68,10 +71,13 @@ def encode_file(in_path, out_path, level=5, verify=False, lax=False, padding=-1,
     return _result(L.flacamd_encode_file(str(in_path).encode(), str(out_path).encode(), C.byref(o), C.byref(res)), res)
 
 
-def decode_file(in_path, out_path, output_format=WAVE, device=0):
+def decode_file(in_path, out_path, output_format=WAVE, device=0, skip=None, until=None):
     L = _lib()
     res = FileResult()
-    return _result(L.flacamd_decode_file(str(in_path).encode(), str(out_path).encode(), output_format, device, C.byref(res)), res)
+    if skip is None and until is None:
+        return _result(L.flacamd_decode_file(str(in_path).encode(), str(out_path).encode(), output_format, device, C.byref(res)), res)
+    return _result(L.flacamd_decode_file_range(str(in_path).encode(), str(out_path).encode(), output_format, device,
+                                               None if skip is None else str(skip).encode(), None if until is None else str(until).encode(), C.byref(res)), res)
 
 
 def main(argv=None):
@@ -93,15 +99,17 @@ def main(argv=None):
     ap.add_argument("-b", "--blocksize", type=int, default=0)
     ap.add_argument("--force-aiff-format", action="store_true")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--skip")
+    ap.add_argument("--until")
     a = ap.parse_args(argv)
     try:
         if a.decode:
             aiff = a.force_aiff_format or a.output_name.lower().endswith((".aif", ".aiff"))
-            r = decode_file(a.input, a.output_name, AIFF if aiff else WAVE, device=a.device)
+            r = decode_file(a.input, a.output_name, AIFF if aiff else WAVE, device=a.device, skip=a.skip, until=a.until)
         else:
             spec = "" if a.no_seektable else None if not a.seekpoint else "".join(s + ";" for s in a.seekpoint)
             r = encode_file(a.input, a.output_name, level=5 if a.level is None else a.level, verify=a.verify, lax=a.lax, padding=a.padding,
-                            seekpoints=spec, tags=a.tag, blocksize=a.blocksize, device=a.device)
+                            seekpoints=spec, tags=a.tag, blocksize=a.blocksize, device=a.device, skip=a.skip, until=a.until)
     except FileError as e:
         print("ERROR: %s" % e)
         return 1

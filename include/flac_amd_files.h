@@ -9,7 +9,10 @@
  * flacamd_decode_file is `flac -d`: src/flac/decode.c :543-790 (WAVE / AIFF headers),
  * :964-1262 (sample formatting).
  *
- * Not provided: Ogg, RF64 / Wave64 containers, FLAC-to-FLAC re-encoding, --skip/--until,
+ * --skip / --until take the tool's values (src/flac/utils.c:170-219; encode.c:1091-1150, :2246-2289;
+ * decode.c:392-399, :1069-1081, :1272-1309).
+ *
+ * Not provided: Ogg, RF64 / Wave64 containers, FLAC-to-FLAC re-encoding,
  * --sector-align, ReplayGain, cue sheet files, pictures, foreign metadata.
  */
 #ifndef FLAC_AMD_FILES_H
@@ -38,6 +41,8 @@ typedef struct {
 	int raw_big_endian, raw_unsigned;                  /* --endian --sign */
 	int device;                     /* HIP device */
 	unsigned batch_frames;          /* frames per device batch, 0 = 4096 */
+	const char *skip;               /* --skip: "123456" (samples) or "mm:ss.sss"; NULL = from the start */
+	const char *until;              /* --until: the same, or "+..." counted from the skip point, "-..." from the end; NULL = to the end */
 } flacamd_file_options;
 
 typedef struct {
@@ -56,6 +61,9 @@ int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd
 
 /* Decode in_path (a native FLAC file) to a WAVE, AIFF or raw PCM file (raw: little-endian, signed). */
 int flacamd_decode_file(const char *in_path, const char *out_path, int output_format, int device, flacamd_file_result *res);
+/* The same for the sample range [skip, until) (`flac -d --skip=.. --until=..`): the header promises the length of the range,
+ * the MD5 verdict is not available for a partial decode (md5_ok = 1).  skip / until as in flacamd_file_options, NULL = not given. */
+int flacamd_decode_file_range(const char *in_path, const char *out_path, int output_format, int device, const char *skip, const char *until, flacamd_file_result *res);
 
 #ifdef __cplusplus
 }

@@ -158,3 +158,57 @@ def test_raw_output_and_errors(gpu_engine, tmp_path):
     assert ei.value.code == -8
     with pytest.raises(files.FileError):
         files.encode_file(src, tmp_path / "b.flac", tags=["no equals sign"])
+
+
+RANGES = [
+    ("wav16-default", "44100", None), ("wav16-default", "0:02.5", "0:10"), ("wav16-default", None, "-3000"), ("wav16-default", "1000", "+0:01.25"),
+    ("wav16-default", "0:21.75", "-0"), ("aiff16", "4097", "-0:00.5"), ("raw16-be", "12345", "40000"), ("wav24-junk-chunks", "0:01", None), ("wav8-mono", None, "5"),
+]
+
+
+@pytest.mark.parametrize("name,skip,until", RANGES)
+def test_encoded_sample_range_equals_the_reference_tools(gpu_engine, tmp_path, name, skip, until):
+    """flac --skip / --until while encoding: the same range, seek table, padding and totals as the tool's file."""
+    c = CASES[name]
+    pcm, blob, fname = _input(c)
+    src = tmp_path / fname
+    src.write_bytes(blob)
+    want, got = tmp_path / "ref.flac", tmp_path / "gpu.flac"
+    rng = (["--skip=" + skip] if skip else []) + (["--until=" + until] if until else [])
+    _ref(["-%d" % c["level"]] + c["tool"] + rng + ["-o", want, src])
+    r = files.encode_file(src, got, level=c["level"], batch_frames=16, skip=skip, until=until, **c["kw"])
+    assert got.read_bytes() == want.read_bytes()
+    assert 0 < r["samples"] < len(pcm)
+
+
+@pytest.mark.parametrize("name,skip,until", RANGES)
+@pytest.mark.parametrize("fmt", ["wave", "aiff"])
+def test_decoded_sample_range_equals_the_reference_tools(gpu_engine, tmp_path, name, skip, until, fmt):
+    """flac -d --skip / --until: the header promises the range, decoding starts inside a frame and stops inside one."""
+    c = CASES[name]
+    pcm, blob, fname = _input(c)
+    src = tmp_path / fname
+    src.write_bytes(blob)
+    flac = tmp_path / "x.flac"
+    files.encode_file(src, flac, level=c["level"], **c["kw"])
+    want, got = tmp_path / ("ref." + fmt), tmp_path / ("gpu." + fmt)
+    rng = (["--skip=" + skip] if skip else []) + (["--until=" + until] if until else [])
+    _ref(["-d"] + (["--force-aiff-format"] if fmt == "aiff" else []) + rng + ["-o", want, flac])
+    r = files.decode_file(flac, got, files.AIFF if fmt == "aiff" else files.WAVE, skip=skip, until=until)
+    assert got.read_bytes() == want.read_bytes()
+    assert 0 < r["samples"] < len(pcm)
+
+
+@pytest.mark.parametrize("skip,until", [("+5", None), ("abc", None), (None, "1:xx"), ("100", "50"), (None, "999999999"), ("999999999", None), (None, "-999999999"), ("0:05", "+0")])
+def test_sample_range_errors(gpu_engine, tmp_path, skip, until):
+    """What the tool refuses is refused: relative --skip, malformed values, --until before the skip point / outside the input."""
+    pcm = synth.music_like(0.5, seed=4)[:20000]
+    src = tmp_path / "a.wav"
+    src.write_bytes(wave_bytes(pcm, 44100, 16))
+    if (skip, until) != ("0:05", "+0"):
+        with pytest.raises(files.FileError):
+            files.encode_file(src, tmp_path / "a.flac", level=1, skip=skip, until=until)
+    flac = tmp_path / "whole.flac"
+    files.encode_file(src, flac, level=1)
+    with pytest.raises(files.FileError):
+        files.decode_file(flac, tmp_path / "a.out.wav", skip=skip, until=until)
