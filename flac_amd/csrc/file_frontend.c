@@ -48,21 +48,49 @@ static unsigned le16(const uint8_t *p) { return (unsigned)p[0] | ((unsigned)p[1]
 static unsigned be16(const uint8_t *p) { return (unsigned)p[1] | ((unsigned)p[0] << 8); }
 static unsigned popcount32(uint32_t v) { unsigned n = 0; for(; v; v &= v - 1) n++; return n; }
 
-/* RIFF WAVE (E:202-679) */
-static int parse_wave(const uint8_t *f, uint64_t size, pcm_input *in, flacamd_file_result *res)
+static uint64_t le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+static const uint8_t W64_RIFF[16] = { 'r','i','f','f', 0x2E,0x91,0xCF,0x11, 0xD6,0xA5,0x28,0xDB, 0x04,0xC1,0x00,0x00 };
+static const uint8_t W64_WAVE[16] = { 'w','a','v','e', 0xF3,0xAC,0xD3,0x11, 0xD1,0x8C,0x00,0xC0, 0x4F,0x8E,0xDB,0x8A };
+static const uint8_t W64_FMT[16]  = { 'f','m','t',' ', 0xF3,0xAC,0xD3,0x11, 0xD1,0x8C,0x00,0xC0, 0x4F,0x8E,0xDB,0x8A };
+static const uint8_t W64_DATA[16] = { 'd','a','t','a', 0xF3,0xAC,0xD3,0x11, 0xD1,0x8C,0x00,0xC0, 0x4F,0x8E,0xDB,0x8A };
+
+/* RIFF WAVE, RF64 (a 'ds64' chunk carries the 64-bit sizes) and Wave64 (16-byte chunk ids, 64-bit sizes that count the
+ * 24-byte chunk header, 8-byte alignment): get_sample_info_wave, E:202-679 */
+static int parse_wave(const uint8_t *f, uint64_t size, int variant, pcm_input *in, flacamd_file_result *res)
 {
-	uint64_t pos = 12; int got_fmt = 0;
+	const int w64 = variant == FLACAMD_FILE_WAVE64, rf64 = variant == FLACAMD_FILE_RF64;
+	const unsigned idlen = w64 ? 16u : 4u, hdr = w64 ? 24u : 8u;
+	uint64_t pos = w64 ? 40 : 12, ds64_data = 0; int got_fmt = 0, got_ds64 = 0;
 	in->big_endian = 0;
-	while(pos + 4 <= size) {
+	while(pos + idlen <= size) {
 		const uint8_t *id = f + pos;
-		uint32_t len;
-		if(pos + 8 > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "incomplete chunk header");
-		len = le32(f + pos + 4);
-		pos += 8;
-		if(0 == memcmp(id, "fmt ", 4)) {
-			unsigned tag; uint32_t body = len;
+		uint64_t len;   /* bytes after the chunk header, as declared */
+		if(pos + hdr > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "incomplete chunk header");
+		if(w64) {
+			len = le64(f + pos + 16);
+			pos += hdr;
+			if(0 == memcmp(id, W64_FMT, 16)) {
+				if(len >> 32) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "freakishly large Wave64 'fmt ' chunk");
+				if(len < 24) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "freakishly small Wave64 'fmt ' chunk");
+			}
+			else if(0 == memcmp(id, W64_DATA, 16)) { if(len < 24) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "freakishly small Wave64 'data' chunk"); }
+			else { len = (len + 7) & ~(uint64_t)7; if(len < 24) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "freakishly small Wave64 chunk"); }
+			len -= 24;
+		}
+		else { len = le32(f + pos + 4); pos += hdr; }
+		if(rf64 && 0 == memcmp(id, "ds64", 4)) {
+			if(got_ds64) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "file has multiple 'ds64' chunks");
+			if(got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "'ds64' chunk appears after 'fmt ' or 'data' chunk");
+			if(len < 28 || pos + len > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'ds64' chunk has length = %u", (unsigned)len);
+			ds64_data = le64(f + pos + 8);
+			got_ds64 = 1;
+			pos += len + (len & 1);
+		}
+		else if(w64 ? 0 == memcmp(id, W64_FMT, 16) : 0 == memcmp(id, "fmt ", 4)) {
+			unsigned tag; const uint64_t body = len;
 			if(got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "file has multiple 'fmt ' chunks");
-			if(body < 16 || pos + body > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'fmt ' chunk has length = %u", body);
+			if(body < 16 || pos + body > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'fmt ' chunk has length = %u", (unsigned)body);
 			tag = le16(f + pos);
 			if(tag != 1 && tag != 65534) return fail(res, FLACAMD_E_UNSUPPORTED, "unsupported format type %u", tag);
 			in->channels = le16(f + pos + 2); in->sample_rate = le32(f + pos + 4); in->bps = le16(f + pos + 14);
@@ -73,7 +101,7 @@ static int parse_wave(const uint8_t *f, uint64_t size, pcm_input *in, flacamd_fi
 			}
 			else {
 				unsigned valid; uint32_t mask;
-				if(body < 40) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid WAVEFORMATEXTENSIBLE chunk with size %u", body);
+				if(body < 40) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid WAVEFORMATEXTENSIBLE chunk with size %u", (unsigned)body);
 				if(le16(f + pos + 16) < 22) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid WAVEFORMATEXTENSIBLE chunk with cbSize %u", le16(f + pos + 16));
 				valid = le16(f + pos + 18);
 				if(valid > in->bps) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "invalid WAVEFORMATEXTENSIBLE chunk with wValidBitsPerSample (%u) > wBitsPerSample (%u)", valid, in->bps);
@@ -88,16 +116,20 @@ static int parse_wave(const uint8_t *f, uint64_t size, pcm_input *in, flacamd_fi
 				in->channel_mask = mask;
 			}
 			got_fmt = 1;
-			pos += (uint64_t)body + (body & 1);
+			pos += w64 ? ((body + 7) & ~(uint64_t)7) : body + (body & 1);
 		}
-		else if(0 == memcmp(id, "data", 4)) {
+		else if(w64 ? 0 == memcmp(id, W64_DATA, 16) : 0 == memcmp(id, "data", 4)) {
 			if(!got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "got 'data' chunk before 'fmt' chunk");
+			if(rf64) {
+				if(!got_ds64) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "RF64 file has no 'ds64' chunk before 'data' chunk");
+				if(len == 0xffffffffu) len = ds64_data;
+			}
 			if(len == 0) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "'data' chunk has size of 0");
 			in->data = f + pos; in->data_bytes = len;
 			in->available_bytes = size - pos < len ? size - pos : len;
 			return 0;
 		}
-		else pos += (uint64_t)len + (len & 1); /* unknown chunk: skipped (E:606-660) */
+		else pos += w64 ? len : len + (len & 1); /* unknown chunk: skipped (E:606-660) */
 	}
 	return fail(res, FLACAMD_E_INVALID_ARGUMENT, got_fmt ? "didn't find data chunk" : "didn't find fmt chunk");
 }
@@ -330,12 +362,22 @@ int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd
 	format = opt->input_format;
 	if(format == FLACAMD_FILE_AUTO) {
 		if(size >= 12 && 0 == memcmp(map, "RIFF", 4) && 0 == memcmp(map + 8, "WAVE", 4)) format = FLACAMD_FILE_WAVE;
+		else if(size >= 12 && 0 == memcmp(map, "RF64", 4) && 0 == memcmp(map + 8, "WAVE", 4)) format = FLACAMD_FILE_RF64;
+		else if(size >= 12 && 0 == memcmp(map, W64_RIFF, 12)) format = FLACAMD_FILE_WAVE64;   /* the tool looks at 12 bytes of the GUID (main.c:1733) */
 		else if(size >= 12 && 0 == memcmp(map, "FORM", 4) && (0 == memcmp(map + 8, "AIFF", 4) || 0 == memcmp(map + 8, "AIFC", 4))) format = FLACAMD_FILE_AIFF;
-		else { rc = fail(res, FLACAMD_E_UNSUPPORTED, "input is neither WAVE nor AIFF; raw input needs input_format = RAW and its parameters"); goto done; }
+		else { rc = fail(res, FLACAMD_E_UNSUPPORTED, "input is neither WAVE, RF64, Wave64 nor AIFF; raw input needs input_format = RAW and its parameters"); goto done; }
 	}
 	if(format == FLACAMD_FILE_WAVE) {
 		if(size < 12 || memcmp(map, "RIFF", 4) || memcmp(map + 8, "WAVE", 4)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not a RIFF WAVE file"); goto done; }
-		rc = parse_wave(map, size, &in, res);
+		rc = parse_wave(map, size, FLACAMD_FILE_WAVE, &in, res);
+	}
+	else if(format == FLACAMD_FILE_RF64) {
+		if(size < 12 || memcmp(map, "RF64", 4) || memcmp(map + 8, "WAVE", 4)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not an RF64 file"); goto done; }
+		rc = parse_wave(map, size, FLACAMD_FILE_RF64, &in, res);
+	}
+	else if(format == FLACAMD_FILE_WAVE64) {
+		if(size < 40 || memcmp(map, W64_RIFF, 12)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not a Wave64 file"); goto done; }
+		rc = parse_wave(map, size, FLACAMD_FILE_WAVE64, &in, res);
 	}
 	else if(format == FLACAMD_FILE_AIFF) {
 		if(size < 12 || memcmp(map, "FORM", 4) || (memcmp(map + 8, "AIFF", 4) && memcmp(map + 8, "AIFC", 4))) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not an AIFF file"); goto done; }
@@ -486,17 +528,29 @@ typedef struct {
 static void w_le(uint8_t *p, uint64_t v, unsigned n) { unsigned i; for(i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * i)); }
 static void w_be(uint8_t *p, uint64_t v, unsigned n) { unsigned i; for(i = 0; i < n; i++) p[i] = (uint8_t)(v >> (8 * (n - 1 - i))); }
 
-/* write_iff_headers (D:543-790) for WAVE and AIFF */
+static int wave_like(int format) { return format == FLACAMD_FILE_WAVE || format == FLACAMD_FILE_RF64 || format == FLACAMD_FILE_WAVE64; }
+
+/* write_iff_headers (D:543-790) for WAVE, RF64, Wave64 and AIFF */
 static int write_header(decode_session *s, FILE *f, FLAC__uint64 samples)
 {
-	uint8_t h[80]; size_t n = 0;
+	uint8_t h[192]; size_t n = 0;
 	const unsigned bytes_per_sample = (s->bps + 7) / 8;
-	const FLAC__uint64 data_size = samples * s->channels * bytes_per_sample, aligned = (data_size + 1) & ~(FLAC__uint64)1;
-	if(s->format == FLACAMD_FILE_WAVE) {
+	const int w64 = s->format == FLACAMD_FILE_WAVE64, rf64 = s->format == FLACAMD_FILE_RF64;
+	const FLAC__uint64 data_size = samples * s->channels * bytes_per_sample, aligned = w64 ? (data_size + 7) & ~(FLAC__uint64)7 : (data_size + 1) & ~(FLAC__uint64)1;
+	if(wave_like(s->format)) {
 		const int ext = s->channel_mask == 2 || s->channel_mask > 3 || (s->bps % 8) || s->channels > 2;
-		const FLAC__uint64 iff = samples == 0 ? 0 : 4 + 8 + (ext ? 40 : 16) + 8 + aligned;
-		if(iff >= 0xFFFFFFF4u) return -1;
-		memcpy(h, "RIFF", 4); w_le(h + 4, iff, 4); memcpy(h + 8, "WAVEfmt ", 8); w_le(h + 16, ext ? 40 : 16, 4); n = 20;
+		const unsigned fmt_body = ext ? 40 : 16;
+		const FLAC__uint64 iff = samples == 0 ? 0 : w64 ? 16 + 8 + 16 + 16 + 8 + fmt_body + 16 + 8 + aligned : 4 + (rf64 ? 36 : 0) + 8 + fmt_body + 8 + aligned;
+		if(s->format == FLACAMD_FILE_WAVE && iff >= 0xFFFFFFF4u) return -1;
+		if(w64) {
+			memcpy(h, W64_RIFF, 16); w_le(h + 16, iff, 8); memcpy(h + 24, W64_WAVE, 16); n = 40;
+			memcpy(h + n, W64_FMT, 16); w_le(h + n + 16, 16 + 8 + fmt_body, 8); n += 24;
+		}
+		else {
+			memcpy(h, rf64 ? "RF64" : "RIFF", 4); w_le(h + 4, rf64 ? 0xffffffffu : iff, 4); memcpy(h + 8, "WAVE", 4); n = 12;
+			if(rf64) { memcpy(h + n, "ds64", 4); w_le(h + n + 4, 28, 4); w_le(h + n + 8, iff, 8); w_le(h + n + 16, data_size, 8); w_le(h + n + 24, samples, 8); w_le(h + n + 32, 0, 4); n += 36; }
+			memcpy(h + n, "fmt ", 4); w_le(h + n + 4, fmt_body, 4); n += 8;
+		}
 		w_le(h + n, ext ? 65534 : 1, 2); w_le(h + n + 2, s->channels, 2); w_le(h + n + 4, s->sample_rate, 4);
 		w_le(h + n + 8, (FLAC__uint64)s->sample_rate * s->channels * bytes_per_sample, 4); w_le(h + n + 12, s->channels * bytes_per_sample, 2);
 		w_le(h + n + 14, bytes_per_sample * 8, 2); n += 16;
@@ -504,7 +558,8 @@ static int write_header(decode_session *s, FILE *f, FLAC__uint64 samples)
 			w_le(h + n, 22, 2); w_le(h + n + 2, s->bps, 2); w_le(h + n + 4, s->channel_mask, 4);
 			memcpy(h + n + 8, "\x01\x00\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71", 16); n += 24;
 		}
-		memcpy(h + n, "data", 4); w_le(h + n + 4, data_size, 4); n += 8;
+		if(w64) { memcpy(h + n, W64_DATA, 16); w_le(h + n + 16, 16 + 8 + data_size, 8); n += 24; }
+		else { memcpy(h + n, "data", 4); w_le(h + n + 4, rf64 ? 0xffffffffu : data_size, 4); n += 8; }
 	}
 	else { /* AIFF */
 		const FLAC__uint64 iff = samples == 0 ? 0 : 46 + aligned;
@@ -552,7 +607,7 @@ static FLAC__StreamDecoderWriteStatus dec_write(const FLAC__StreamDecoder *d, co
 	decode_session *s = (decode_session*)cd;
 	const unsigned bps = fr->header.bits_per_sample, ch = fr->header.channels; unsigned n = fr->header.blocksize;
 	const unsigned shift = (s->format != FLACAMD_FILE_RAW && (bps % 8)) ? 8 - (bps % 8) : 0, width = (bps + shift + 7) / 8;
-	const int big = s->format == FLACAMD_FILE_AIFF, uns = s->format == FLACAMD_FILE_WAVE && bps <= 8;
+	const int big = s->format == FLACAMD_FILE_AIFF, uns = wave_like(s->format) && bps <= 8;
 	const int32_t bias = uns ? (int32_t)1 << (bps + shift - 1) : 0;
 	unsigned i, c; uint8_t *p; size_t need;
 	(void)d;
@@ -592,7 +647,7 @@ int flacamd_decode_file_range(const char *in_path, const char *out_path, int out
 	range_spec sk, un;
 	if(res) memset(res, 0, sizeof *res);
 	if(!in_path || !out_path) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "missing path");
-	if(output_format != FLACAMD_FILE_WAVE && output_format != FLACAMD_FILE_AIFF && output_format != FLACAMD_FILE_RAW) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "unknown output format %d", output_format);
+	if(!wave_like(output_format) && output_format != FLACAMD_FILE_AIFF && output_format != FLACAMD_FILE_RAW) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "unknown output format %d", output_format);
 	if((rc = parse_range_options(skip, until, &sk, &un, res)) != 0) return rc;
 	memset(&s, 0, sizeof s);
 	s.format = output_format; s.res = res;
@@ -632,7 +687,8 @@ int flacamd_decode_file_range(const char *in_path, const char *out_path, int out
 	if(!rc && !s.header_written && s.got_streaminfo && s.format != FLACAMD_FILE_RAW) { if(write_header(&s, s.out, 0) != 0) rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "writing the header"); s.header_written = 1; } /* a stream without frames */
 	if(!rc && s.format != FLACAMD_FILE_RAW) {
 		const FLAC__uint64 data_size = s.written_samples * s.channels * ((s.bps + 7) / 8);
-		if(data_size & 1) fputc(0, s.out);                                     /* pad byte (D:415-441) */
+		unsigned pad = s.format == FLACAMD_FILE_WAVE64 ? (8u - (unsigned)(data_size & 7)) & 7u : (unsigned)(data_size & 1);   /* D:415-441 */
+		for(; pad > 0; pad--) fputc(0, s.out);
 		if(s.total_samples == 0 && s.written_samples > 0) { /* sizes were unknown up front: go back and fix the header (D:941-962) */
 			fflush(s.out);
 			if(fseeko(s.out, 0, SEEK_SET) != 0 || write_header(&s, s.out, s.written_samples) != 0) rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "fixing up the header");

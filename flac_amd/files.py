@@ -5,7 +5,7 @@ import ctypes as C
 
 from . import engine
 
-AUTO, RAW, WAVE, AIFF = range(4)
+AUTO, RAW, WAVE, AIFF, RF64, WAVE64 = range(6)
 
 
 class FileOptions(C.Structure):
@@ -98,14 +98,18 @@ def main(argv=None):
     ap.add_argument("-T", "--tag", action="append", default=[])
     ap.add_argument("-b", "--blocksize", type=int, default=0)
     ap.add_argument("--force-aiff-format", action="store_true")
+    ap.add_argument("--force-rf64-format", action="store_true")
+    ap.add_argument("--force-wave64-format", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--skip")
     ap.add_argument("--until")
     a = ap.parse_args(argv)
     try:
         if a.decode:
-            aiff = a.force_aiff_format or a.output_name.lower().endswith((".aif", ".aiff"))
-            r = decode_file(a.input, a.output_name, AIFF if aiff else WAVE, device=a.device, skip=a.skip, until=a.until)
+            low = a.output_name.lower()   # the tool's rules (src/flac/main.c:2020-2040)
+            fmt = (AIFF if a.force_aiff_format or low.endswith((".aif", ".aiff")) else RF64 if a.force_rf64_format or low.endswith(".rf64")
+                   else WAVE64 if a.force_wave64_format or low.endswith(".w64") else WAVE)
+            r = decode_file(a.input, a.output_name, fmt, device=a.device, skip=a.skip, until=a.until)
         else:
             spec = "" if a.no_seektable else None if not a.seekpoint else "".join(s + ";" for s in a.seekpoint)
             r = encode_file(a.input, a.output_name, level=5 if a.level is None else a.level, verify=a.verify, lax=a.lax, padding=a.padding,

@@ -1,7 +1,7 @@
 /* Whole-file front end over the libFLAC-style objects of flac_amd_stream.h.
  *
  * flacamd_encode_file does what `flac [options] in.wav -o out.flac` does in the reference's
- * command-line tool for PCM inputs (src/flac/encode.c: WAVE/AIFF/raw parsing :188-907, sample
+ * command-line tool for PCM inputs (src/flac/encode.c: WAVE/RF64/Wave64/AIFF/raw parsing :188-907, sample
  * formatting :2338-2428, metadata layout :2016-2053, encoder set-up :2066-2149) and writes the
  * same bytes: STREAMINFO, the seek table (a point every 10 s unless told otherwise), the tag
  * block, padding, frames.  The input file is memory-mapped and handed to the encoder object in
@@ -12,7 +12,7 @@
  * --skip / --until take the tool's values (src/flac/utils.c:170-219; encode.c:1091-1150, :2246-2289;
  * decode.c:392-399, :1069-1081, :1272-1309).
  *
- * Not provided: Ogg, RF64 / Wave64 containers, FLAC-to-FLAC re-encoding,
+ * Not provided: Ogg, FLAC-to-FLAC re-encoding,
  * --sector-align, ReplayGain, cue sheet files, pictures, foreign metadata.
  */
 #ifndef FLAC_AMD_FILES_H
@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-enum { FLACAMD_FILE_AUTO = 0, FLACAMD_FILE_RAW = 1, FLACAMD_FILE_WAVE = 2, FLACAMD_FILE_AIFF = 3 };
+enum { FLACAMD_FILE_AUTO = 0, FLACAMD_FILE_RAW = 1, FLACAMD_FILE_WAVE = 2, FLACAMD_FILE_AIFF = 3,
+       FLACAMD_FILE_RF64 = 4, FLACAMD_FILE_WAVE64 = 5 };   /* the 64-bit WAVE variants (--force-rf64-format, --force-wave64-format) */
 
 typedef struct {
 	unsigned compression_level;     /* 0..8: flac -0 .. -8 */
@@ -59,7 +60,7 @@ void flacamd_file_options_init(flacamd_file_options *opt);
 /* 0 on success, a FLACAMD_E_* code (flac_amd_engine.h) otherwise; res->error says what failed. */
 int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd_file_options *opt, flacamd_file_result *res);
 
-/* Decode in_path (a native FLAC file) to a WAVE, AIFF or raw PCM file (raw: little-endian, signed). */
+/* Decode in_path (a native FLAC file) to a WAVE, RF64, Wave64, AIFF or raw PCM file (raw: little-endian, signed). */
 int flacamd_decode_file(const char *in_path, const char *out_path, int output_format, int device, flacamd_file_result *res);
 /* The same for the sample range [skip, until) (`flac -d --skip=.. --until=..`): the header promises the length of the range,
  * the MD5 verdict is not available for a partial decode (md5_ok = 1).  skip / until as in flacamd_file_options, NULL = not given. */

@@ -212,3 +212,88 @@ def test_sample_range_errors(gpu_engine, tmp_path, skip, until):
     files.encode_file(src, flac, level=1)
     with pytest.raises(files.FileError):
         files.decode_file(flac, tmp_path / "a.out.wav", skip=skip, until=until)
+
+
+_W64 = {k: (k.encode() + b"\xF3\xAC\xD3\x11\xD1\x8C\x00\xC0\x4F\x8E\xDB\x8A") for k in ("wave", "fmt ", "data", "junk")}
+_W64["riff"] = b"riff\x2E\x91\xCF\x11\xD6\xA5\x28\xDB\x04\xC1\x00\x00"
+
+
+def _fmt_body(pcm, rate, bps, extensible, mask):
+    ch, width = pcm.shape[1], (bps + 7) // 8
+    fmt = struct.pack("<HHIIHH", 65534 if extensible else 1, ch, rate, rate * ch * width, ch * width, width * 8)
+    if extensible:
+        fmt += struct.pack("<HHI", 22, bps, mask) + b"\x01\x00\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+    return fmt
+
+
+def rf64_bytes(pcm, rate, bps, extensible=False, mask=0, extra=b"", data_size_in_chunk=False):
+    width = (bps + 7) // 8
+    data = _pack(pcm, width, unsigned=bps <= 8, shift=8 * width - bps)
+    fmt = _fmt_body(pcm, rate, bps, extensible, mask)
+    tail = b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra + b"data" + struct.pack("<I", len(data) if data_size_in_chunk else 0xFFFFFFFF) + data + (b"\0" if len(data) & 1 else b"")
+    ds64 = b"ds64" + struct.pack("<IQQQI", 28, 4 + 36 + len(tail), len(data), len(pcm), 0)
+    return b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + ds64 + tail
+
+
+def wave64_bytes(pcm, rate, bps, extensible=False, mask=0, junk=b""):
+    width = (bps + 7) // 8
+    data = _pack(pcm, width, unsigned=bps <= 8, shift=8 * width - bps)
+    fmt = _fmt_body(pcm, rate, bps, extensible, mask)
+
+    def chunk(guid, body):
+        return guid + struct.pack("<Q", 24 + len(body)) + body + b"\0" * (-len(body) % 8)
+    body = _W64["wave"] + chunk(_W64["fmt "], fmt) + (chunk(_W64["junk"], junk) if junk else b"") + chunk(_W64["data"], data)
+    return _W64["riff"] + struct.pack("<Q", 24 + len(body)) + body
+
+
+WIDE_CASES = {
+    "rf64-16": dict(make=lambda p: rf64_bytes(p, 44100, 16), ch=2, bps=16, rate=44100, seconds=2.0, name="in.rf64"),
+    "rf64-24-6ch-extra": dict(make=lambda p: rf64_bytes(p, 48000, 24, extensible=True, mask=0x3f, extra=b"LIST" + struct.pack("<I", 3) + b"abc\0", data_size_in_chunk=True),
+                              ch=6, bps=24, rate=48000, seconds=0.8, name="in.rf64"),
+    "w64-16": dict(make=lambda p: wave64_bytes(p, 44100, 16, junk=b"12345"), ch=2, bps=16, rate=44100, seconds=2.0, name="in.w64"),
+    "w64-8-mono-odd": dict(make=lambda p: wave64_bytes(p[:-3], 22050, 8), ch=1, bps=8, rate=22050, seconds=0.7, name="in.w64", drop=3),
+    "w64-20in24": dict(make=lambda p: wave64_bytes(p, 96000, 20, extensible=True, mask=0x3), ch=2, bps=20, rate=96000, seconds=0.5, name="in.w64"),
+}
+
+
+def _wide_pcm(c):
+    n = int(c["seconds"] * c["rate"])
+    base = synth.music_like(c["seconds"] + 0.1, rate=c["rate"], seed=c["ch"] + c["bps"])[:n]
+    pcm = np.stack([base[:, i % 2].astype(np.int64) for i in range(c["ch"])], axis=1)
+    return (pcm << max(0, c["bps"] - 16)) >> max(0, 16 - c["bps"])
+
+
+@pytest.mark.parametrize("name", sorted(WIDE_CASES))
+def test_rf64_and_wave64_input_equals_the_reference_tools(gpu_engine, tmp_path, name):
+    c = WIDE_CASES[name]
+    pcm = _wide_pcm(c)
+    src = tmp_path / c["name"]
+    src.write_bytes(c["make"](pcm))
+    want, got = tmp_path / "ref.flac", tmp_path / "gpu.flac"
+    _ref(["-6", "-o", want, src])
+    r = files.encode_file(src, got, level=6, batch_frames=16)
+    assert got.read_bytes() == want.read_bytes()
+    assert r["samples"] == len(pcm) - c.get("drop", 0) and r["bits_per_sample"] == c["bps"]
+
+
+@pytest.mark.parametrize("name", ["wav16-default", "wav8-mono", "wavext-6ch-24", "wavext-20in24", "aiff12-mono-offset"])
+@pytest.mark.parametrize("fmt", ["rf64", "w64"])
+def test_decoded_rf64_and_wave64_equal_the_reference_tools(gpu_engine, tmp_path, name, fmt):
+    """flac -d --force-rf64-format / --force-wave64-format, whole and as a sample range (odd byte counts: the pad rules differ)."""
+    c = CASES[name]
+    pcm, blob, fname = _input(c)
+    src = tmp_path / fname
+    src.write_bytes(blob)
+    flac = tmp_path / "x.flac"
+    files.encode_file(src, flac, level=c["level"], **c["kw"])
+    for skip, until in ((None, None), ("777", "-0:00.1")):
+        want, got = tmp_path / ("ref." + fmt), tmp_path / ("gpu." + fmt)
+        rng = (["--skip=" + skip] if skip else []) + (["--until=" + until] if until else [])
+        _ref(["-d", "-f", "--force-rf64-format" if fmt == "rf64" else "--force-wave64-format"] + rng + ["-o", want, flac])
+        files.decode_file(flac, got, files.RF64 if fmt == "rf64" else files.WAVE64, skip=skip, until=until)
+        assert got.read_bytes() == want.read_bytes()
+        # and back in: the file just written is read like the tool reads it
+        back_ref, back_gpu = tmp_path / "back_ref.flac", tmp_path / "back_gpu.flac"
+        _ref(["-f", "-3", "-o", back_ref, want])
+        files.encode_file(got, back_gpu, level=3)
+        assert back_gpu.read_bytes() == back_ref.read_bytes()
