@@ -8,6 +8,7 @@
 #include "../../include/flac_amd_files.h"
 #include "../../include/flac_amd_stream.h"
 #include "../../include/flac_amd_engine.h"
+#include "metadata_blocks.h"
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -332,6 +333,202 @@ static int parse_range_options(const char *skip, const char *until, range_spec *
 	return 0;
 }
 
+/* The tag block of the command line (-T values), with the channel mask tag set when the input names a mask: the first
+ * tag of that name is replaced where it stands, later ones are dropped, none: appended (src/flac/utils.c:279-297,
+ * FLAC__metadata_object_vorbiscomment_replace_comment with all=true).  *entries_out is the caller's to free. */
+static int build_tags(const flacamd_file_options *opt, uint32_t channel_mask, FLAC__StreamMetadata *tags, FLAC__StreamMetadata_VorbisComment_Entry **entries_out,
+	char *mask_tag, size_t mask_tag_cap, flacamd_file_result *res)
+{
+	unsigned i, n = opt->num_tags, length = 8;
+	FLAC__StreamMetadata_VorbisComment_Entry *entries = (FLAC__StreamMetadata_VorbisComment_Entry*)calloc(n + 1, sizeof *entries);
+	if(!entries) return fail(res, FLACAMD_E_OUT_OF_MEMORY, "allocating memory for tags");
+	*entries_out = entries;
+	for(i = 0; i < n; i++) {
+		const size_t l = strlen(opt->tags[i]);
+		if(!FLAC__format_vorbiscomment_entry_is_legal((const FLAC__byte*)opt->tags[i], (unsigned)l)) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "illegal tag \"%s\"", opt->tags[i]);
+		entries[i].length = (FLAC__uint32)l; entries[i].entry = (FLAC__byte*)opt->tags[i];
+		length += 4 + (unsigned)l;
+	}
+	if(channel_mask) {
+		const size_t name = strlen(CHANNEL_MASK_TAG);
+		unsigned w = 0; int placed = 0;
+		snprintf(mask_tag, mask_tag_cap, "%s=0x%04X", CHANNEL_MASK_TAG, (unsigned)channel_mask);
+		for(i = 0; i < n; i++) {
+			const int same = entries[i].length > name && entries[i].entry[name] == '=' && 0 == strncasecmp((const char*)entries[i].entry, CHANNEL_MASK_TAG, name);
+			if(!same) { entries[w++] = entries[i]; continue; }
+			length -= 4 + entries[i].length;
+			if(!placed) { entries[w].length = (FLAC__uint32)strlen(mask_tag); entries[w].entry = (FLAC__byte*)mask_tag; length += 4 + entries[w].length; w++; placed = 1; }
+		}
+		n = w;
+		if(!placed) { entries[n].length = (FLAC__uint32)strlen(mask_tag); entries[n].entry = (FLAC__byte*)mask_tag; length += 4 + entries[n].length; n++; }
+	}
+	memset(tags, 0, sizeof *tags);
+	tags->type = FLAC__METADATA_TYPE_VORBIS_COMMENT; tags->length = length;
+	tags->data.vorbis_comment.num_comments = n; tags->data.vorbis_comment.comments = n ? entries : 0;
+	return 0;
+}
+
+/* WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x... of a tag block: flac__utils_get_channel_mask_tag (src/flac/utils.c:299-321) */
+static uint32_t channel_mask_of(const FLAC__StreamMetadata *m)
+{
+	const size_t name = strlen(CHANNEL_MASK_TAG); unsigned i;
+	for(i = 0; i < m->data.vorbis_comment.num_comments; i++) {
+		const FLAC__StreamMetadata_VorbisComment_Entry *e = &m->data.vorbis_comment.comments[i];
+		if(e->length > name + 3 && 0 == strncasecmp((const char*)e->entry, CHANNEL_MASK_TAG, name) && e->entry[name] == '=' && 0 == strncmp((const char*)e->entry + name + 1, "0x", 2)) {
+			unsigned v;
+			return sscanf((const char*)e->entry + name + 3, "%x", &v) == 1 ? v : 0;
+		}
+	}
+	return 0;
+}
+
+/* ---- FLAC input: decode on the device, code again, keep the metadata the way the tool does (E:907-958, :1746-2015, :2524-2557) ---- */
+#define MAX_INPUT_BLOCKS 64   /* FLACDecoderData.metadata_blocks[] */
+typedef struct { FLAC__StreamEncoder *enc; FLAC__uint64 left; int failed; flacamd_file_result *res; } recode_session;
+
+static FLAC__StreamDecoderWriteStatus recode_write(const FLAC__StreamDecoder *d, const FLAC__Frame *fr, const FLAC__int32 * const buffer[], void *cd)
+{
+	recode_session *r = (recode_session*)cd;
+	const FLAC__uint64 n = r->left < fr->header.blocksize ? r->left : fr->header.blocksize;
+	(void)d;
+	if(n && !FLAC__stream_encoder_process(r->enc, buffer, (unsigned)n)) {
+		r->failed = 1; fail(r->res, FLACAMD_E_DEVICE, "during encoding: %s", FLAC__stream_encoder_get_resolved_state_string(r->enc));
+		return FLAC__STREAM_DECODER_WRITE_STATUS_ABORT;
+	}
+	r->left -= n;
+	return FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE;
+}
+static void recode_error(const FLAC__StreamDecoder *d, FLAC__StreamDecoderErrorStatus st, void *cd)
+{
+	recode_session *r = (recode_session*)cd; (void)d;
+	r->failed = 1; fail(r->res, FLACAMD_E_BAD_STREAM, "got %s while decoding FLAC input", FLAC__StreamDecoderErrorStatusString[st]);
+}
+
+static int encode_flac_input(const uint8_t *map, uint64_t size, const char *in_path, const char *out_path, const flacamd_file_options *opt, flacamd_file_result *res)
+{
+	FLAC__StreamMetadata in_blocks[MAX_INPUT_BLOCKS], ours_tags, ours_seek, ours_pad, *list[MAX_INPUT_BLOCKS + 4];
+	unsigned nin = 0, nlist = 0, i, j, channels, bps, rate; uint64_t pos = 4, total_in, total, skip, until;
+	FLAC__StreamMetadata_VorbisComment_Entry *entries = 0; char mask_tag[64]; point_list points = { 0, 0, 0, 0 };
+	FLAC__StreamEncoder *enc = 0; FLAC__StreamDecoder *dec = 0; recode_session rs; int rc = 0, last = 0, have_tags = 0, have_seek = 0; long pad_sum = -1;
+	uint32_t channel_mask = 0;
+	range_spec sk, un;
+
+	/* the blocks of the input, STREAMINFO first (E:940-951) */
+	if(size < 4 + 4 + 34 || (map[4] & 0x7f) != FLAC__METADATA_TYPE_STREAMINFO || ((uint32_t)map[5] << 16 | (uint32_t)map[6] << 8 | map[7]) < 34)
+		return fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input, first metadata block is not STREAMINFO");
+	{
+		const uint8_t *si = map + 8;
+		rate = (unsigned)si[10] << 12 | (unsigned)si[11] << 4 | si[12] >> 4;
+		channels = ((si[12] >> 1) & 7u) + 1u; bps = (((unsigned)si[12] & 1u) << 4 | si[13] >> 4) + 1u;
+		total_in = ((uint64_t)(si[13] & 15u) << 32) | be32(si + 14);
+	}
+	if(total_in == 0) return fail(res, FLACAMD_E_UNSUPPORTED, "FLAC input has STREAMINFO with unknown total samples which is not supported");
+	while(!last) {
+		uint32_t len; unsigned type;
+		if(pos + 4 > size) { rc = fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input"); goto done; }
+		last = map[pos] >> 7; type = map[pos] & 0x7f; len = (uint32_t)map[pos + 1] << 16 | (uint32_t)map[pos + 2] << 8 | map[pos + 3];
+		pos += 4;
+		if(pos + len > size) { rc = fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input"); goto done; }
+		if(type != FLAC__METADATA_TYPE_STREAMINFO) {
+			if(nin + 1 >= MAX_INPUT_BLOCKS) { rc = fail(res, FLACAMD_E_UNSUPPORTED, "out of memory or too many metadata blocks while reading metadata in FLAC input"); goto done; }
+			if(flacamd_metadata_block_parse(type, last, map + pos, len, &in_blocks[nin]) != 0) { rc = fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input"); goto done; }
+			nin++;
+		}
+		pos += len;
+	}
+
+	/* the sample range (E:1083, :1091-1150) */
+	if((rc = parse_range_options(opt->skip, opt->until, &sk, &un, res)) != 0) goto done;
+	canonicalize_range_spec(&sk, rate);
+	skip = (uint64_t)sk.samples;
+	if((rc = canonicalize_until(&un, rate, skip, total_in, res)) != 0) goto done;
+	until = (uint64_t)un.samples;
+	if(skip >= total_in) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "while skipping samples"); goto done; }
+	total = total_in - skip - (until > 0 ? total_in - until : 0);
+
+	/* tags: the command line's replace the input's, which hand on their channel mask; none in the input: an empty block (E:1810-1849) */
+	for(i = 0; i < nin; i++) if(in_blocks[i].type == FLAC__METADATA_TYPE_VORBIS_COMMENT) { have_tags = 1; if(opt->num_tags > 0) channel_mask = channel_mask_of(&in_blocks[i]); }
+	/* seek table: -S- drops it, -S values replace it, an unchanged length keeps the input's, else the default (E:1906-1957) */
+	for(i = 0; i < nin; i++) if(in_blocks[i].type == FLAC__METADATA_TYPE_SEEKTABLE && !(total != total_in || opt->seekpoints)) have_seek = 1;
+	if((opt->seekpoints && opt->seekpoints[0]) || (!opt->seekpoints && !have_seek)) {
+		seek_template(opt->seekpoints ? opt->seekpoints : "10s;", total, rate, &points);
+		if(points.failed) { rc = fail(res, FLACAMD_E_OUT_OF_MEMORY, "allocating memory for seek table"); goto done; }
+		memset(&ours_seek, 0, sizeof ours_seek);
+		ours_seek.type = FLAC__METADATA_TYPE_SEEKTABLE; ours_seek.length = points.n * FLAC__STREAM_METADATA_SEEKPOINT_LENGTH;
+		ours_seek.data.seek_table.num_points = points.n; ours_seek.data.seek_table.points = points.pts;
+		list[nlist++] = &ours_seek;
+	}
+	if(!have_tags || opt->num_tags > 0) {
+		if((rc = build_tags(opt, channel_mask, &ours_tags, &entries, mask_tag, sizeof mask_tag, res)) != 0) goto done;
+		list[nlist++] = &ours_tags;
+	}
+	for(i = 0; i < nin; i++) {
+		const FLAC__StreamMetadata *m = &in_blocks[i];
+		if(m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT && opt->num_tags > 0) continue;
+		if(m->type == FLAC__METADATA_TYPE_SEEKTABLE && !have_seek) continue;
+		if(m->type == FLAC__METADATA_TYPE_CUESHEET && (m->data.cue_sheet.num_tracks == 0 || total != m->data.cue_sheet.tracks[m->data.cue_sheet.num_tracks - 1].offset)) continue;   /* lead-out no longer at the end (E:1856-1893) */
+		if(m->type == FLAC__METADATA_TYPE_PADDING) { if(pad_sum < 0) pad_sum = 0; pad_sum += (long)m->length; continue; }   /* all padding becomes one block at the end (E:1960-2002) */
+		list[nlist++] = &in_blocks[i];
+	}
+	if(opt->padding > 0) pad_sum = opt->padding;
+	if(pad_sum < 0) pad_sum = total / rate < 20 * 60 ? DEFAULT_PADDING : DEFAULT_PADDING * 8;
+	if(opt->padding != 0 && pad_sum > 0) {
+		memset(&ours_pad, 0, sizeof ours_pad);
+		ours_pad.type = FLAC__METADATA_TYPE_PADDING; ours_pad.length = (unsigned)pad_sum;
+		list[nlist++] = &ours_pad;
+	}
+
+	enc = FLAC__stream_encoder_new();
+	dec = FLAC__stream_decoder_new();
+	if(!enc || !dec) { rc = fail(res, FLACAMD_E_OUT_OF_MEMORY, "creating the encoder instance"); goto done; }
+	FLAC__stream_encoder_set_verify(enc, opt->verify);
+	FLAC__stream_encoder_set_streamable_subset(enc, !opt->lax);
+	FLAC__stream_encoder_set_channels(enc, channels);
+	FLAC__stream_encoder_set_bits_per_sample(enc, bps);
+	FLAC__stream_encoder_set_sample_rate(enc, rate);
+	FLAC__stream_encoder_set_compression_level(enc, opt->compression_level);
+	if(opt->blocksize) FLAC__stream_encoder_set_blocksize(enc, opt->blocksize);
+	FLAC__stream_encoder_set_total_samples_estimate(enc, total);
+	FLAC__stream_encoder_set_metadata(enc, nlist ? list : 0, nlist);
+	flacamd_stream_encoder_set_device(enc, opt->device);
+	flacamd_stream_encoder_set_batch_frames(enc, opt->batch_frames ? opt->batch_frames : 4096u);
+	{
+		const FLAC__StreamEncoderInitStatus is = FLAC__stream_encoder_init_file(enc, out_path, 0, 0);
+		if(is != FLAC__STREAM_ENCODER_INIT_STATUS_OK) {
+			rc = fail(res, is == FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR ? FLACAMD_E_DEVICE : FLACAMD_E_INVALID_ARGUMENT, "initializing encoder: %s (%s)",
+				FLAC__StreamEncoderInitStatusString[is], FLAC__stream_encoder_get_resolved_state_string(enc));
+			goto done;
+		}
+	}
+	memset(&rs, 0, sizeof rs);
+	rs.enc = enc; rs.left = total; rs.res = res;
+	FLAC__stream_decoder_set_md5_checking(dec, 0);
+	flacamd_stream_decoder_set_device(dec, opt->device);
+	if(FLAC__stream_decoder_init_file(dec, in_path, recode_write, 0, recode_error, &rs) != FLAC__STREAM_DECODER_INIT_STATUS_OK) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "initializing decoder for FLAC input, state = %s", FLAC__stream_decoder_get_resolved_state_string(dec)); goto done; }
+	if(!FLAC__stream_decoder_process_until_end_of_metadata(dec)) { rc = fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input, state = %s", FLAC__stream_decoder_get_resolved_state_string(dec)); goto done; }
+	if(skip > 0 && !FLAC__stream_decoder_seek_absolute(dec, skip)) { rc = fail(res, FLACAMD_E_BAD_STREAM, "while skipping samples, FLAC decoder state = %s", FLAC__stream_decoder_get_resolved_state_string(dec)); goto done; }   /* E:1247 */
+	while(!rs.failed && rs.left > 0) { /* E:1440-1455 */
+		if(!FLAC__stream_decoder_process_single(dec) || FLAC__stream_decoder_get_state(dec) == FLAC__STREAM_DECODER_END_OF_STREAM) {
+			if(rs.left > 0 && !rs.failed) rc = fail(res, FLACAMD_E_BAD_STREAM, "while decoding FLAC input, state = %s", FLAC__stream_decoder_get_resolved_state_string(dec));
+			break;
+		}
+	}
+	if(rs.failed && !rc) rc = FLACAMD_E_BAD_STREAM;
+	if(rc) goto done;
+	if(!FLAC__stream_encoder_finish(enc)) { rc = fail(res, FLACAMD_E_DEVICE, "finishing the stream: %s", FLAC__stream_encoder_get_resolved_state_string(enc)); goto done; }
+	if(res) {
+		struct stat os;
+		res->samples = total - rs.left; res->channels = channels; res->bits_per_sample = bps; res->sample_rate = rate; res->md5_ok = 1;
+		if(stat(out_path, &os) == 0) res->bytes_written = (uint64_t)os.st_size;
+	}
+done:
+	if(dec) { (void)FLAC__stream_decoder_finish(dec); FLAC__stream_decoder_delete(dec); }
+	if(enc) { if(rc) (void)FLAC__stream_encoder_finish(enc); FLAC__stream_encoder_delete(enc); }
+	for(j = 0; j < nin; j++) flacamd_metadata_block_free(&in_blocks[j]);
+	free(entries); free(points.pts);
+	return rc;
+}
+
 int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd_file_options *opt, flacamd_file_result *res)
 {
 	flacamd_file_options defaults;
@@ -364,8 +561,14 @@ int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd
 		if(size >= 12 && 0 == memcmp(map, "RIFF", 4) && 0 == memcmp(map + 8, "WAVE", 4)) format = FLACAMD_FILE_WAVE;
 		else if(size >= 12 && 0 == memcmp(map, "RF64", 4) && 0 == memcmp(map + 8, "WAVE", 4)) format = FLACAMD_FILE_RF64;
 		else if(size >= 12 && 0 == memcmp(map, W64_RIFF, 12)) format = FLACAMD_FILE_WAVE64;   /* the tool looks at 12 bytes of the GUID (main.c:1733) */
+		else if(size >= 4 && 0 == memcmp(map, "fLaC", 4)) format = FLACAMD_FILE_FLAC;
 		else if(size >= 12 && 0 == memcmp(map, "FORM", 4) && (0 == memcmp(map + 8, "AIFF", 4) || 0 == memcmp(map + 8, "AIFC", 4))) format = FLACAMD_FILE_AIFF;
 		else { rc = fail(res, FLACAMD_E_UNSUPPORTED, "input is neither WAVE, RF64, Wave64 nor AIFF; raw input needs input_format = RAW and its parameters"); goto done; }
+	}
+	if(format == FLACAMD_FILE_FLAC) {
+		if(size < 4 || memcmp(map, "fLaC", 4)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not a FLAC file"); goto done; }
+		rc = encode_flac_input(map, size, in_path, out_path, opt, res);
+		goto done;
 	}
 	if(format == FLACAMD_FILE_WAVE) {
 		if(size < 12 || memcmp(map, "RIFF", 4) || memcmp(map + 8, "WAVE", 4)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "not a RIFF WAVE file"); goto done; }
@@ -426,35 +629,8 @@ int flacamd_encode_file(const char *in_path, const char *out_path, const flacamd
 			blocks[nblocks++] = &seektable;
 		}
 	}
-	{
-		unsigned i, n = opt->num_tags, length = 8;
-		entries = (FLAC__StreamMetadata_VorbisComment_Entry*)calloc(n + 1, sizeof *entries);
-		if(!entries) { rc = fail(res, FLACAMD_E_OUT_OF_MEMORY, "allocating memory for tags"); goto done; }
-		for(i = 0; i < n; i++) {
-			const size_t l = strlen(opt->tags[i]);
-			if(!FLAC__format_vorbiscomment_entry_is_legal((const FLAC__byte*)opt->tags[i], (unsigned)l)) { rc = fail(res, FLACAMD_E_INVALID_ARGUMENT, "illegal tag \"%s\"", opt->tags[i]); goto done; }
-			entries[i].length = (FLAC__uint32)l; entries[i].entry = (FLAC__byte*)opt->tags[i];
-			length += 4 + (unsigned)l;
-		}
-		if(in.channel_mask) { /* the first tag of that name is replaced where it stands, later ones are dropped, none: appended
-		                       * (src/flac/utils.c:279-297, FLAC__metadata_object_vorbiscomment_replace_comment with all=true) */
-			const size_t name = strlen(CHANNEL_MASK_TAG);
-			unsigned w = 0; int placed = 0;
-			snprintf(mask_tag, sizeof mask_tag, "%s=0x%04X", CHANNEL_MASK_TAG, (unsigned)in.channel_mask);
-			for(i = 0; i < n; i++) {
-				const int same = entries[i].length > name && entries[i].entry[name] == '=' && 0 == strncasecmp((const char*)entries[i].entry, CHANNEL_MASK_TAG, name);
-				if(!same) { entries[w++] = entries[i]; continue; }
-				length -= 4 + entries[i].length;
-				if(!placed) { entries[w].length = (FLAC__uint32)strlen(mask_tag); entries[w].entry = (FLAC__byte*)mask_tag; length += 4 + entries[w].length; w++; placed = 1; }
-			}
-			n = w;
-			if(!placed) { entries[n].length = (FLAC__uint32)strlen(mask_tag); entries[n].entry = (FLAC__byte*)mask_tag; length += 4 + entries[n].length; n++; }
-		}
-		memset(&tags, 0, sizeof tags);
-		tags.type = FLAC__METADATA_TYPE_VORBIS_COMMENT; tags.length = length;
-		tags.data.vorbis_comment.num_comments = n; tags.data.vorbis_comment.comments = n ? entries : 0;
-		blocks[nblocks++] = &tags;
-	}
+	if((rc = build_tags(opt, in.channel_mask, &tags, &entries, mask_tag, sizeof mask_tag, res)) != 0) goto done;
+	blocks[nblocks++] = &tags;
 	if(opt->padding != 0) {
 		memset(&padding, 0, sizeof padding);
 		padding.type = FLAC__METADATA_TYPE_PADDING;

@@ -5,7 +5,7 @@ import ctypes as C
 
 from . import engine
 
-AUTO, RAW, WAVE, AIFF, RF64, WAVE64 = range(6)
+AUTO, RAW, WAVE, AIFF, RF64, WAVE64, FLAC = range(7)
 
 
 class FileOptions(C.Structure):

@@ -12,7 +12,10 @@
  * --skip / --until take the tool's values (src/flac/utils.c:170-219; encode.c:1091-1150, :2246-2289;
  * decode.c:392-399, :1069-1081, :1272-1309).
  *
- * Not provided: Ogg, FLAC-to-FLAC re-encoding,
+ * A native FLAC file as input is decoded on the device and coded again, its metadata kept, replaced or dropped by the
+ * tool's rules (src/flac/encode.c:907-958, :1746-2015).
+ *
+ * Not provided: Ogg,
  * --sector-align, ReplayGain, cue sheet files, pictures, foreign metadata.
  */
 #ifndef FLAC_AMD_FILES_H
@@ -25,7 +28,8 @@ extern "C" {
 #endif
 
 enum { FLACAMD_FILE_AUTO = 0, FLACAMD_FILE_RAW = 1, FLACAMD_FILE_WAVE = 2, FLACAMD_FILE_AIFF = 3,
-       FLACAMD_FILE_RF64 = 4, FLACAMD_FILE_WAVE64 = 5 };   /* the 64-bit WAVE variants (--force-rf64-format, --force-wave64-format) */
+       FLACAMD_FILE_RF64 = 4, FLACAMD_FILE_WAVE64 = 5,
+       FLACAMD_FILE_FLAC = 6 };   /* encode only: a native FLAC file as input */   /* the 64-bit WAVE variants (--force-rf64-format, --force-wave64-format) */
 
 typedef struct {
 	unsigned compression_level;     /* 0..8: flac -0 .. -8 */

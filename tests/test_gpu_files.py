@@ -297,3 +297,55 @@ def test_decoded_rf64_and_wave64_equal_the_reference_tools(gpu_engine, tmp_path,
         _ref(["-f", "-3", "-o", back_ref, want])
         files.encode_file(got, back_gpu, level=3)
         assert back_gpu.read_bytes() == back_ref.read_bytes()
+
+
+def _png(w=4, h=3):
+    import zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    raw = b"".join(b"\0" + bytes([i * 20 % 256] * (w * 3)) for i in range(h))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+RECODE = [
+    ("plain", [], {}, [], {}),
+    ("tags-kept", ["-T", "ARTIST=x", "-T", "TITLE=y z", "-S", "1s", "--padding=300"], dict(tags=["ARTIST=x", "TITLE=y z"], seekpoints="1s;", padding=300), [], {}),
+    ("tags-replaced", ["-T", "ARTIST=x"], dict(tags=["ARTIST=x"]), ["-T", "ALBUM=q"], dict(tags=["ALBUM=q"])),
+    ("seek-dropped", ["-S", "0.5s"], dict(seekpoints="0.5s;"), ["-S-", "--no-padding"], dict(seekpoints="", padding=0)),
+    ("seek-replaced-pad", ["-S", "0.5s"], dict(seekpoints="0.5s;"), ["-S", "3x", "-P", "77"], dict(seekpoints="3x;", padding=77)),
+    ("range", ["-T", "A=b", "-S", "1s"], dict(tags=["A=b"], seekpoints="1s;"), ["--skip=0:01", "--until=-5000"], dict(skip="0:01", until="-5000")),
+    ("picture-cuesheet", ["PICTURE", "CUESHEET"], None, [], {}),
+    ("picture-cuesheet-range", ["PICTURE", "CUESHEET"], None, ["--until=0:02"], dict(until="0:02")),
+    ("mask-carried", ["6CH"], None, ["-T", "X=y"], dict(tags=["X=y"])),
+]
+
+
+@pytest.mark.parametrize("name,first_tool,first_kw,tool,kw", RECODE, ids=[r[0] for r in RECODE])
+def test_flac_input_is_coded_again_like_the_reference_tools(gpu_engine, tmp_path, name, first_tool, first_kw, tool, kw):
+    """FLAC in, FLAC out: decoded on the device and coded again; tags, seek table, padding, pictures and cue sheets kept,
+    replaced or dropped as the tool does it (src/flac/encode.c:1746-2015)."""
+    rate, n = 44100, 44100 * 3
+    six = "6CH" in first_tool
+    pcm = synth.music_like(3.1, seed=12)[:n]
+    if six:
+        pcm = np.stack([pcm[:, i % 2] // (i + 1) for i in range(6)], axis=1)
+    src = tmp_path / "in.wav"
+    src.write_bytes(wave_bytes(pcm, rate, 16, extensible=six, mask=0x3f if six else 0))
+    first = tmp_path / "first.flac"
+    extra = []
+    if "PICTURE" in first_tool:
+        (tmp_path / "p.png").write_bytes(_png())
+        (tmp_path / "c.cue").write_text('FILE "in.wav" WAVE\n  TRACK 01 AUDIO\n    INDEX 01 00:00:00\n  TRACK 02 AUDIO\n    INDEX 01 00:01:37\n')
+        extra = ["--picture=3|image/png|cover||" + str(tmp_path / "p.png"), "--cuesheet=" + str(tmp_path / "c.cue")]
+    if first_kw is None:
+        _ref(["-2"] + extra + ["-o", first, src])
+    else:
+        _ref(["-2"] + first_tool + ["-o", first, src])
+        mine = tmp_path / "first_gpu.flac"
+        files.encode_file(src, mine, level=2, **first_kw)
+        assert mine.read_bytes() == first.read_bytes()
+    want, got = tmp_path / "ref.flac", tmp_path / "gpu.flac"
+    _ref(["-7"] + tool + ["-o", want, first])
+    r = files.encode_file(first, got, level=7, batch_frames=8, **kw)
+    assert got.read_bytes() == want.read_bytes()
+    assert r["channels"] == pcm.shape[1] and 0 < r["samples"] <= n
