@@ -349,6 +349,7 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 {
 	if(!e) return;
 	hipSetDevice(e->device);
+	if(e->q_n) { (void)hipStreamSynchronize(e->q_stream); e->q_n = 0; }   // queued batches still use the work arrays
 	for(int i = 0; i < 7; i++) if(e->ev[i]) (void)hipEventDestroy(e->ev[i]);
 	if(e->qev_made) for(uint32_t b = 0; b < FLACAMD_QUEUE_DEPTH; b++) for(int i = 0; i < 7; i++) (void)hipEventDestroy(e->qev[b][i]);
 	if(e->side) (void)hipStreamDestroy(e->side);
