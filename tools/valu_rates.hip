@@ -33,6 +33,18 @@ __global__ void __launch_bounds__(256) NAME(int *out, int a, int b) { \
 #define A_LSHLADD(x) "v_lshl_add_u32 " #x ", %8, 2, " #x
 #define A_MULF(x) "v_mul_f32 " #x ", %8, " #x
 #define A_PKFMA(x) "v_pk_fma_f32 " #x ", %8, %9, " #x
+#define A_ALIGNBIT(x) "v_alignbit_b32 " #x ", %8, " #x ", 7"
+#define A_PERM(x) "v_perm_b32 " #x ", %8, " #x ", %9"
+#define A_BFE(x) "v_bfe_i32 " #x ", " #x ", 3, 16"
+#define A_MOV(x) "v_mov_b32 " #x ", %8"
+#define A_CNDMASK(x) "v_cndmask_b32 " #x ", %8, " #x ", vcc"
+#define A_XOR(x) "v_xor_b32 " #x ", %8, " #x
+DEF_KERNEL(k_alignbit, A_ALIGNBIT)
+DEF_KERNEL(k_perm, A_PERM)
+DEF_KERNEL(k_bfe, A_BFE)
+DEF_KERNEL(k_mov, A_MOV)
+DEF_KERNEL(k_cndmask, A_CNDMASK)
+DEF_KERNEL(k_xor, A_XOR)
 DEF_KERNEL(k_mad24, A_MAD24)
 DEF_KERNEL(k_mul24, A_MUL24)
 DEF_KERNEL(k_add, A_ADD)
@@ -61,6 +73,30 @@ __global__ void __launch_bounds__(256) k_mad64(long long *out, int a, int b) {
 	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
+// 64-bit and packed-float instructions: four independent chains on register pairs
+#define DEF_KERNEL64(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(long long *out, int a, int b) { \
+	long long x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; \
+	long long va = a + threadIdx.x; int vb = (b ^ threadIdx.x) & 15; \
+	for(int i = 0; i < ITERS; i++) { \
+		asm volatile(ASM(%0) "\n" ASM(%1) "\n" ASM(%2) "\n" ASM(%3) "\n" ASM(%0) "\n" ASM(%1) "\n" ASM(%2) "\n" ASM(%3) \
+			: "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(va), "v"(vb)); \
+	} \
+	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3; \
+}
+#define A_ASHR64(x) "v_ashrrev_i64 " #x ", %5, " #x
+#define A_LSHLADD64(x) "v_lshl_add_u64 " #x ", " #x ", 0, %4"
+#define A_PKMULF(x) "v_pk_mul_f32 " #x ", %4, " #x
+#define A_PKADDF(x) "v_pk_add_f32 " #x ", %4, " #x
+#define A_PKFMAF(x) "v_pk_fma_f32 " #x ", %4, %4, " #x
+#define A_FMA64(x) "v_fma_f64 " #x ", %4, %4, " #x
+DEF_KERNEL64(k_ashr64, A_ASHR64)
+DEF_KERNEL64(k_lshladd64, A_LSHLADD64)
+DEF_KERNEL64(k_pkmulf, A_PKMULF)
+DEF_KERNEL64(k_pkaddf, A_PKADDF)
+DEF_KERNEL64(k_pkfmaf, A_PKFMAF)
+DEF_KERNEL64(k_fma64, A_FMA64)
+
 template<typename K, typename T>
 static void run(const char *name, K kern, T *buf)
 {
@@ -86,5 +122,8 @@ int main()
 	run("max_i32", k_maxi, buf); run("fma_f32", k_fma, buf); run("mul_f32", k_mulf, buf); run("mad_i32_i16", k_madi16, buf); run("pk_mad_i16", k_pkmad, buf);
 	run("ashrrev_i32", k_ashr, buf); run("lshl_add_u32", k_lshladd, buf);
 	run("mad_i64_i32", k_mad64, (long long*)buf);
+	run("alignbit_b32", k_alignbit, buf); run("perm_b32", k_perm, buf); run("bfe_i32", k_bfe, buf); run("mov_b32", k_mov, buf); run("cndmask_b32", k_cndmask, buf); run("xor_b32", k_xor, buf);
+	run("ashrrev_i64", k_ashr64, (long long*)buf); run("lshl_add_u64", k_lshladd64, (long long*)buf);
+	run("pk_mul_f32", k_pkmulf, (long long*)buf); run("pk_add_f32", k_pkaddf, (long long*)buf); run("pk_fma_f32", k_pkfmaf, (long long*)buf); run("fma_f64", k_fma64, (long long*)buf);
 	return 0;
 }
