@@ -135,12 +135,14 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			else {
 				const uint32_t tt = t - cg, ci = tt / (HIST / 2), m = tt - ci * (HIST / 2);
 				const bool ok = cb + ci < c.max_cand;
-				// rows at and above the candidate's order are not written by the model stage: read them as zero
-				const uint32_t ord = ok ? FA_CAND_ORDER(w.cand_hdr[fa_cand_idx(c, g, (cb + ci))]) : 0u;
-				int32_t q0 = (ok && 2u * m < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + 2u * m] : 0;
-				int32_t q1 = (ok && 2u * m + 1u < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + 2u * m + 1u] : 0;
-				if(2u * m >= ord) q0 = 0;
-				if(2u * m + 1u >= ord) q1 = 0;
+				// header and coefficient pair fetched side by side (a slot that does not exist reads the signal's first record
+				// instead, a row the coefficient table does not have reads row 0: no load hangs on a condition another load decides);
+				// rows at and above the candidate's order are not written by the model stage: taken as zero
+				const size_t rec = fa_cand_idx(c, g, ok ? cb + ci : 0u);
+				const uint32_t hdr_ci = w.cand_hdr[rec];
+				const int32_t l0 = w.cand_q[rec + (2u * m < qrows ? 2u * m : 0u)], l1 = w.cand_q[rec + (2u * m + 1u < qrows ? 2u * m + 1u : 0u)];
+				const uint32_t ord = ok ? FA_CAND_ORDER(hdr_ci) : 0u;
+				const int32_t q0 = (2u * m < ord && 2u * m < qrows) ? l0 : 0, q1 = (2u * m + 1u < ord && 2u * m + 1u < qrows) ? l1 : 0;
 				cq[ci * HIST + 2u * m] = q0; cq[ci * HIST + 2u * m + 1u] = q1;
 				cqp[tt] = pack_lo16(q0, q1);
 			}
