@@ -239,7 +239,7 @@ __device__ __forceinline__ void flush_words(uint32_t *bitbuf, uint32_t total_bit
 }
 
 template<bool SPILL>
-__global__ void __launch_bounds__(256) fa_pack_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+__global__ void __launch_bounds__(256, 3) fa_pack_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackShared sh;
