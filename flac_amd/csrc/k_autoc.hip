@@ -25,17 +25,19 @@
 
 #define AC_STEP 16
 
-// 16 raw wide samples of a 16-bit stereo stream: one dword (left | right << 16) each
-struct Raw16 { uint4 v[4]; };
+// 16 raw wide samples of a stereo stream: PK = 1: one dword (left | right << 16) each (16-bit samples as they lie in a
+// 16-bit stream), PK = 2: two dwords (left, right) each (the 32-bit layout process_interleaved hands over)
+template<int PK> struct RawStereo { uint4 v[4 * PK]; };
 
-__device__ __forceinline__ uint32_t raw_get(const Raw16 &r, int j)
+template<int PK>
+__device__ __forceinline__ uint32_t raw_dword(const RawStereo<PK> &r, int d)
 {
-	const uint4 &q = r.v[j >> 2];
-	return (j & 3) == 0 ? q.x : (j & 3) == 1 ? q.y : (j & 3) == 2 ? q.z : q.w;
+	const uint4 &q = r.v[d >> 2];
+	return (d & 3) == 0 ? q.x : (d & 3) == 1 ? q.y : (d & 3) == 2 ? q.z : q.w;
 }
 
-// Fast path: 16-bit stereo, mid/side analysis (signals L, R, M, S), blocksize a multiple of 16.
-template<int LAG>
+// Fast path: stereo with mid/side analysis (signals L, R, M, S), blocksize a multiple of 16; PK as above.
+template<int LAG, int PK>
 __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
 {
 	// These waves are few (one lane per signal) and each is a long serial chain: they go first wherever they share a SIMD
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const uint32_t gg = active ? g : c.G - 1u;
 	const uint32_t f = gg >> 2, s = gg & 3u;
 	const uint32_t n = fa_frame_len(c, w, f);
-	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N;
+	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N * (uint32_t)PK;   // dwords
 	const uint32_t f0 = (blockIdx.x * 64u) >> 2;
 	const uint32_t nloop = (!c.multi && f0 + 1 == c.F) ? c.last_n : c.N;   // short frames in between: their lanes add zeros past their end
 	// signal = (ca * left + cb * right) >> cs: L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), wasted bits left in
@@ -55,17 +57,18 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const uint32_t sh = s == 2u ? 1u : 0u;
 
 	auto load16 = [&](uint32_t i0) {
-		Raw16 r;
+		RawStereo<PK> r;
 		if(i0 + AC_STEP <= n) {
-			const uint4 *q = (const uint4*)(p + i0);
-			r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+			const uint4 *q = (const uint4*)(p + (size_t)i0 * PK);
+#pragma unroll
+			for(int j = 0; j < 4 * PK; j++) r.v[j] = q[j];
 		}
 		else { // tail of a short last block: never read past the end of the stream
-			uint32_t t[AC_STEP];
+			uint32_t t[AC_STEP * PK];
 #pragma unroll
-			for(int j = 0; j < AC_STEP; j++) t[j] = (i0 + (uint32_t)j < n) ? p[i0 + j] : 0u;
+			for(int j = 0; j < AC_STEP * PK; j++) t[j] = (i0 + (uint32_t)(j / PK) < n) ? p[(size_t)i0 * PK + j] : 0u;
 #pragma unroll
-			for(int j = 0; j < 4; j++) r.v[j] = make_uint4(t[4*j], t[4*j+1], t[4*j+2], t[4*j+3]);
+			for(int j = 0; j < 4 * PK; j++) r.v[j] = make_uint4(t[4*j], t[4*j+1], t[4*j+2], t[4*j+3]);
 		}
 		return r;
 	};
@@ -88,15 +91,16 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 		for(int i = 0; i < NP; i++) A[i] = (f2){0.0f, 0.0f};
 #pragma unroll
 		for(int i = 0; i < T / 2; i++) { E[i] = (f2){0.0f, 0.0f}; O[i] = (f2){0.0f, 0.0f}; }
-		Raw16 nxt = load16(0);
+		RawStereo<PK> nxt = load16(0);
 		for(uint32_t i0 = 0; i0 < nloop; i0 += AC_STEP) {
-			const Raw16 cur = nxt;
+			const RawStereo<PK> cur = nxt;
 			if(i0 + AC_STEP < nloop) nxt = load16(i0 + AC_STEP);
 #pragma unroll
 			for(int j = 0; j < AC_STEP; j++) {
-				const uint32_t lr = raw_get(cur, j);
-				const int32_t l = (int32_t)(int16_t)(lr & 0xffffu), r = (int32_t)lr >> 16;
-				const int32_t x = (ca * l + cb * r) >> sh;
+				int32_t l, r;
+				if(PK == 1) { const uint32_t lr = raw_dword(cur, j); l = (int32_t)(int16_t)(lr & 0xffffu); r = (int32_t)lr >> 16; }
+				else { l = (int32_t)raw_dword(cur, 2 * j); r = (int32_t)raw_dword(cur, 2 * j + 1); }
+				const int32_t x = PK == 1 ? (ca * l + cb * r) >> sh : (int32_t)((uint32_t)ca * (uint32_t)l + (uint32_t)cb * (uint32_t)r) >> sh;   // (32-bit wrapping, like fa_signal)
 				const uint32_t i = i0 + (uint32_t)j;
 				// lpc.c:60; samples past the end of a short block are zero (raw is zero there and the
 				// window index is clamped to stay inside the table)
@@ -203,11 +207,15 @@ __global__ void __launch_bounds__(64) fa_autoc_kernel(const void *__restrict__ p
 extern "C" void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w, hipStream_t st)
 {
 	const dim3 grid((c->G + 63u) / 64u), block(64);
-	const bool ms16 = c->midside && c->pcm_format == FLACAMD_PCM_S16 && (c->N % AC_STEP) == 0 && ((uintptr_t)pcm % 16u) == 0;
-	if(ms16) {
-		if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_ms16_kernel<9>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
-		else if(c->lag <= 13) hipLaunchKernelGGL(fa_autoc_ms16_kernel<13>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
-		else hipLaunchKernelGGL(fa_autoc_ms16_kernel<33>, grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+	const bool ms = c->midside && c->channels == 2u && (c->N % AC_STEP) == 0 && ((uintptr_t)pcm % 16u) == 0;
+	if(ms && c->pcm_format == FLACAMD_PCM_S16) {
+		if(c->lag <= 9) hipLaunchKernelGGL((fa_autoc_ms16_kernel<9, 1>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		else if(c->lag <= 13) hipLaunchKernelGGL((fa_autoc_ms16_kernel<13, 1>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		else hipLaunchKernelGGL((fa_autoc_ms16_kernel<33, 1>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+	}
+	else if(ms && c->pcm_format == FLACAMD_PCM_S32 && c->lag <= 13) {   // (lag 33 with 32 raw dwords in flight twice over would not fit the register file)
+		if(c->lag <= 9) hipLaunchKernelGGL((fa_autoc_ms16_kernel<9, 2>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		else hipLaunchKernelGGL((fa_autoc_ms16_kernel<13, 2>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
 	}
 	else {
 		if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_kernel<9>, grid, block, 0, st, pcm, *c, *w);

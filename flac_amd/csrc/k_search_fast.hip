@@ -540,7 +540,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 // 3.8 ms; tighter caps (5 or 6 workgroups) gain 2 % and spill 80-100 bytes per lane; evaluating three
 // candidates side by side in a wave spills and gains nothing.  Other sample layouts take the general kernel.
 template<typename SUM, int PK, int LIGHT>
-__global__ void __launch_bounds__(SF_THREADS, 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__global__ void __launch_bounds__(SF_THREADS, (PK == 2 || sizeof(SUM) == 8) ? 3 : 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
 	sf_body<SUM, PK, LIGHT>(pcm, c, w, cg);
 }
