@@ -74,10 +74,11 @@ __device__ __forceinline__ void lpc_pred_each(const int32_t (&xw)[W], const int3
 			pred = acc >> shift;
 		}
 		else {
-			uint32_t acc = 0;
+			// the wrapping 32-bit sum is the low word of the 64-bit one: one v_mad_i64_i32 per tap instead of a multiply and an add
+			long long acc = 0;
 #pragma unroll
-			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
-			pred = (int32_t)acc >> shift;
+			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+			pred = (int32_t)(uint32_t)acc >> shift;
 		}
 		f(s, xw[HIST + s], pred, P);
 	}
@@ -159,10 +160,10 @@ __device__ __forceinline__ void lpc_each(const int32_t (&xw)[W], const int32_t (
 			pred = acc >> shift;
 		}
 		else {
-			uint32_t acc = 0;
+			long long acc = 0;   // (low word = the wrapping 32-bit sum, as above)
 #pragma unroll
-			for(int j = 0; j < P; j++) acc += (uint32_t)q[j] * (uint32_t)xw[HIST + s - 1 - j];
-			pred = (int32_t)acc >> shift;
+			for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+			pred = (int32_t)(uint32_t)acc >> shift;
 		}
 		f(s, (int32_t)((uint32_t)xw[HIST + s] - (uint32_t)pred), P);
 	}
