@@ -70,7 +70,8 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 }
 
 // PK = 1: 16-bit stereo (left/right, plus mid/side when analysed), one packed dword per wide sample;
-// PK = 2: the same from 32-bit samples (what process_interleaved hands over).
+// PK = 2: the same from 32-bit samples (what process_interleaved hands over);
+// PK = 3, 4: one channel, 16-bit and 32-bit samples.
 // LIGHT = 1: no candidate of the stream can need the 64-bit prediction sum or more than 24-bit
 // samples (decided on the host), so those paths and their registers are compiled out.
 template<typename SUM, int PK, int LIGHT>
@@ -160,7 +161,31 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		// one group unless a precision search multiplies the candidates) so that they do not occupy
 		// registers during the evaluation phase; issued before anything waits
 		int32_t xw[SF_W];
-		if(PK == 1) {
+		if(PK == 4) {   // one channel, 32-bit samples: a dword per sample, rows of four
+			uint32_t raw[SF_W];
+#pragma unroll
+			for(int j = 0; j < SF_W / 4; j++) {
+				const int32_t rel = (int32_t)i0 - HIST + 4 * j;
+				uint4 v = make_uint4(0u, 0u, 0u, 0u);
+				if(active && rel >= 0) v = *(const uint4*)((const uint32_t*)pcm + base + (uint32_t)rel);
+				raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
+			}
+#pragma unroll
+			for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)raw[j] >> wasted;
+		}
+		else if(PK == 3) {   // one channel, 16-bit samples: four to an 8-byte load
+			uint32_t raw[SF_W / 2];
+#pragma unroll
+			for(int j = 0; j < SF_W / 4; j++) {
+				const int32_t rel = (int32_t)i0 - HIST + 4 * j;
+				uint2 v = make_uint2(0u, 0u);
+				if(active && rel >= 0) v = *(const uint2*)((const uint16_t*)pcm + base + (uint32_t)rel);
+				raw[2*j] = v.x; raw[2*j+1] = v.y;
+			}
+#pragma unroll
+			for(int j = 0; j < SF_W / 2; j++) { xw[2*j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> wasted; xw[2*j+1] = (int32_t)raw[j] >> (16u + wasted); }
+		}
+		else if(PK == 1) {
 			uint32_t raw[SF_W];
 #pragma unroll
 			for(int j = 0; j < SF_W / 4; j++) {
@@ -540,7 +565,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 // 3.8 ms; tighter caps (5 or 6 workgroups) gain 2 % and spill 80-100 bytes per lane; evaluating three
 // candidates side by side in a wave spills and gains nothing.  Other sample layouts take the general kernel.
 template<typename SUM, int PK, int LIGHT>
-__global__ void __launch_bounds__(SF_THREADS, (PK == 2 || sizeof(SUM) == 8) ? 3 : 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
+__global__ void __launch_bounds__(SF_THREADS, (PK == 2 || sizeof(SUM) == 8 || (PK == 4 && !LIGHT)) ? 3 : 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
 	sf_body<SUM, PK, LIGHT>(pcm, c, w, cg);
 }
@@ -559,7 +584,8 @@ extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum6
 // 16 samples, at most 64 of them, and predictor orders within the register window.
 extern "C" int fa_search_fast_ok(const void *pcm, const FaCfg *c)
 {
-	if(c->channels != 2u || ((uintptr_t)pcm % 16u) != 0) return 0;   // stereo, rows of 4 (16-bit) or 2 (32-bit) wide samples per 16-byte load
+	if((c->channels != 2u && c->channels != 1u) || ((uintptr_t)pcm % 16u) != 0) return 0;
+	if(c->channels == 1u && (c->debug & 0x2000000u)) return 0;   // one or two channels, whole aligned rows of samples per load
 	if(c->N > (uint32_t)(SF_THREADS * SF_CH) || (c->N % SF_CH) != 0 || c->max_lpc_order > (uint32_t)HIST || (c->debug & 0x800u)) return 0;
 	uint32_t tz = 0;
 	while(!((c->N >> tz) & 1u)) tz++;
@@ -573,7 +599,7 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 	if(frames == 0) return;
 	const size_t lds = fa_search_fast_lds_bytes(c, cg, sum64);
 	const dim3 grid(frames * c->nsig), block(SF_THREADS);
-	const int pk = c->pcm_format == FLACAMD_PCM_S16 ? 1 : 2;
+	const int pk = c->channels == 1u ? (c->pcm_format == FLACAMD_PCM_S16 ? 3 : 4) : (c->pcm_format == FLACAMD_PCM_S16 ? 1 : 2);
 	// can any candidate take the 64-bit prediction sum (stream_encoder.c:3597-3603: bps + precision + ilog2(order) > 32)
 	// or carry more than 24-bit samples?
 	uint32_t lg = 0;
@@ -584,9 +610,11 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 #define SF_LAUNCH(SUMT, PKV, LV) do { \
 		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV, LV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
-	if(sum64) { if(pk == 1) SF_LAUNCH(unsigned long long, 1, 0); else SF_LAUNCH(unsigned long long, 2, 0); }
-	else if(light) { if(pk == 1) SF_LAUNCH(uint32_t, 1, 1); else SF_LAUNCH(uint32_t, 2, 1); }
-	else { if(pk == 1) SF_LAUNCH(uint32_t, 1, 0); else SF_LAUNCH(uint32_t, 2, 0); }
+#define SF_LAUNCH_PK(SUMT, LV) do { if(pk == 1) SF_LAUNCH(SUMT, 1, LV); else if(pk == 2) SF_LAUNCH(SUMT, 2, LV); else if(pk == 3) SF_LAUNCH(SUMT, 3, LV); else SF_LAUNCH(SUMT, 4, LV); } while(0)
+	if(sum64) SF_LAUNCH_PK(unsigned long long, 0);
+	else if(light) SF_LAUNCH_PK(uint32_t, 1);
+	else SF_LAUNCH_PK(uint32_t, 0);
+#undef SF_LAUNCH_PK
 #undef SF_LAUNCH
 
 }
