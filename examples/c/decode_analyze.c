@@ -1,5 +1,5 @@
 /* A libFLAC client: FLAC file in, 16-bit WAVE file and an analysis listing out.  The listing has the layout of the
- * reference tool's analysis mode (src/flac/analyze.c:61-125, without residuals): it reads FLAC__Frame.header,
+ * reference tool's analysis mode (src/flac/analyze.c:61-125, residuals as a digest per subframe): it reads FLAC__Frame.header,
  * .subframes[] (type, wasted bits, order, coefficients, warm-up samples, partition order, Rice parameters) and the
  * decode position.  Compiled against include/flac_amd_stream.h + libflacamd.so and against the reference's headers
  * and library; both builds must write the same two files (tests/test_gpu_c_client.py).  Call sequence of the
@@ -28,6 +28,15 @@ static void list_rice(const FLAC__EntropyCodingMethod *m)
 	}
 }
 
+/* a digest of the values a subframe carried (every residual, or every sample of a verbatim subframe), so that two
+ * decoders can be compared on them without a listing of millions of lines */
+static unsigned long digest(const FLAC__int32 *v, unsigned n)
+{
+	unsigned long h = 2166136261ul; unsigned i;
+	for(i = 0; i < n; i++) { h ^= (unsigned long)(FLAC__uint32)v[i]; h = (h * 16777619ul) & 0xfffffffful; }
+	return h;
+}
+
 static FLAC__StreamDecoderWriteStatus on_frame(const FLAC__StreamDecoder *dec, const FLAC__Frame *frame, const FLAC__int32 * const buffer[], void *client_data)
 {
 	unsigned c, i; FLAC__uint64 pos = 0;
@@ -46,12 +55,13 @@ static FLAC__StreamDecoderWriteStatus on_frame(const FLAC__StreamDecoder *dec, c
 		const FLAC__Subframe *s = &frame->subframes[c];
 		fprintf(ana, "\tsubframe=%u\twasted_bits=%u\ttype=%s", c, s->wasted_bits, FLAC__SubframeTypeString[s->type]);
 		if(s->type == FLAC__SUBFRAME_TYPE_CONSTANT) fprintf(ana, "\tvalue=%d\n", s->data.constant.value);
-		else if(s->type == FLAC__SUBFRAME_TYPE_VERBATIM) fprintf(ana, "\n");
+		else if(s->type == FLAC__SUBFRAME_TYPE_VERBATIM) fprintf(ana, "\tdata_digest=%08lx\n", digest(s->data.verbatim.data, frame->header.blocksize));
 		else if(s->type == FLAC__SUBFRAME_TYPE_FIXED) {
 			const int r2 = s->data.fixed.entropy_coding_method.type == FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2;
 			fprintf(ana, "\torder=%u\tresidual_type=%s\tpartition_order=%u\n", s->data.fixed.order, r2 ? "RICE2" : "RICE", s->data.fixed.entropy_coding_method.data.partitioned_rice.order);
 			for(i = 0; i < s->data.fixed.order; i++) fprintf(ana, "\t\twarmup[%u]=%d\n", i, s->data.fixed.warmup[i]);
 			list_rice(&s->data.fixed.entropy_coding_method);
+			fprintf(ana, "\t\tresidual_digest=%08lx\n", digest(s->data.fixed.residual, frame->header.blocksize - s->data.fixed.order));
 		}
 		else {
 			const int r2 = s->data.lpc.entropy_coding_method.type == FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2;
@@ -60,6 +70,7 @@ static FLAC__StreamDecoderWriteStatus on_frame(const FLAC__StreamDecoder *dec, c
 			for(i = 0; i < s->data.lpc.order; i++) fprintf(ana, "\t\tqlp_coeff[%u]=%d\n", i, s->data.lpc.qlp_coeff[i]);
 			for(i = 0; i < s->data.lpc.order; i++) fprintf(ana, "\t\twarmup[%u]=%d\n", i, s->data.lpc.warmup[i]);
 			list_rice(&s->data.lpc.entropy_coding_method);
+			fprintf(ana, "\t\tresidual_digest=%08lx\n", digest(s->data.lpc.residual, frame->header.blocksize - s->data.lpc.order));
 		}
 	}
 	fprintf(ana, "\tfooter_crc=%04x\theader_crc=%02x\n", (unsigned)frame->footer.crc, (unsigned)frame->header.crc);

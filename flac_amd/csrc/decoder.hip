@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				const uint32_t method = br.read(2);
 				if(method > 1u) { ex = 4; ok = false; break; }                               // :2580
 				po = br.read(4); plen = method ? 5u : 4u; esc = method ? 31u : 15u;
-				if(sub) sub->head = type | (order << 2) | (wasted << 8) | (prec_read << 13) | (method << 18) | (po << 19) | (shift_read << 23);
+				if(sub) sub->head = type | (order << 2) | (wasted << 8) | (prec_read << 13) | (method << 18) | (po << 19) | (shift_read << 23) | (wide << 28);
 				if(po == 0) { if(n < order) { ex = 1; ok = false; break; } } else if((n >> po) < order) { ex = 1; ok = false; break; } // :2732-2745
 				// a blocksize that the partition count does not divide: the reference reads (n >> po) samples per partition
 				// all the same (:2727) and leaves the rest of the block undefined
@@ -1023,6 +1023,49 @@ __global__ void __launch_bounds__(256) fd_finalize_kernel(FdCfg c, FdWork w, voi
 	}
 }
 
+// What the stream carried for every subframe, for clients that analyse it (FLAC__Subframe_Fixed::residual,
+// FLAC__Subframe_LPC::residual, FLAC__Subframe_Verbatim::data of include/FLAC/format.h:283-352; src/flac/analyze.c:61-125
+// prints them).  The decode kernel hands residuals from its parser to its restorer through LDS and keeps none of
+// them, so they are formed again here from the restored signal, which unlike the restore is parallel in the sample
+// index: r[j] = x[order + j] - prediction(x[j .. order + j - 1]), with the prediction summed the way the decoder
+// summed it (wrapping 32-bit or 64-bit, the subframe record's bit 28; stream_decoder.c:2682-2692, lpc.c:795-1321,
+// fixed.c:395-435).  One workgroup per accepted frame and channel; the output has the layout of FLACAMD_PCM_S32_FRAMES
+// (frame after frame, channel after channel), entry j of a channel's row being the subframe's j-th residual (or j-th
+// verbatim sample); rows of constant subframes and the last `order` entries of a row are left as they are.
+__global__ void __launch_bounds__(256) fd_residual_kernel(FdCfg c, FdWork w, int32_t *__restrict__ out)
+{
+	if((w.result[4] & (c.tolerant ? ~(uint64_t)3 : ~(uint64_t)0)) != 0) return;
+	const uint32_t r = blockIdx.x / c.channels, ch = blockIdx.x - r * c.channels;
+	if(r >= (uint32_t)w.result[0]) return;
+	const uint32_t ci = w.frame_of[r];
+	const uint32_t n = w.cand_bs[ci];
+	const flacamd_subframe_info *rec = w.subinfo + ((size_t)ci * c.channels + ch);
+	const uint32_t head = rec->head, type = head & 3u, order = (head >> 2) & 63u, wasted = (head >> 8) & 31u, wide = (head >> 28) & 1u;
+	const uint32_t lv = (head >> 23) & 31u;
+	const uint32_t shift = (lv & 16u) ? 0u : lv;   // a negative level: the decode kernel restores with shift 0 (see there)
+	const int32_t *x = w.ws + ((size_t)ci * c.channels + ch) * c.ws_stride;
+	int32_t *o = out + w.sample_off[r] * c.channels + (size_t)ch * n;
+	if(type == 0u || order > n) return;
+	__shared__ int32_t q[FLACAMD_MAX_LPC_ORDER];
+	if(type == 3u && threadIdx.x < order) q[threadIdx.x] = rec->q[threadIdx.x];
+	__syncthreads();
+	for(uint32_t j = threadIdx.x; j + order < n; j += 256) {
+		const int32_t *p = x + j + order;   // the sample the residual belongs to; its history lies below
+		const int32_t cur = p[0] >> wasted;
+		int32_t pred = 0;
+		if(type == 2u) {
+			const uint32_t a = order > 0 ? (uint32_t)(p[-1] >> wasted) : 0u, b = order > 1 ? (uint32_t)(p[-2] >> wasted) : 0u,
+				cc = order > 2 ? (uint32_t)(p[-3] >> wasted) : 0u, d = order > 3 ? (uint32_t)(p[-4] >> wasted) : 0u;
+			pred = (int32_t)(order == 1 ? a : order == 2 ? 2u * a - b : order == 3 ? 3u * a - 3u * b + cc : order == 4 ? 4u * a - 6u * b + 4u * cc - d : 0u);
+		}
+		else if(type == 3u) {
+			if(wide) { long long sum = 0; for(uint32_t t = 0; t < order; t++) sum += (long long)q[t] * (long long)(p[-1 - (int)t] >> wasted); pred = (int32_t)(sum >> shift); }
+			else { uint32_t sum = 0; for(uint32_t t = 0; t < order; t++) sum += (uint32_t)q[t] * (uint32_t)(p[-1 - (int)t] >> wasted); pred = (int32_t)sum >> shift; }
+		}
+		o[j] = (int32_t)((uint32_t)cur - (uint32_t)pred);
+	}
+}
+
 // ------------------------------------------------------------------ host side
 
 static thread_local char fd_last_error[256] = "";
@@ -1036,6 +1079,8 @@ struct flacamd_decoder {
 	void *d_in_stage; void *d_pcm_stage; size_t pcm_stage_bytes;
 	uint32_t last_ncand, last_nframes, last_damage;
 	void *d_subinfo;
+	void *d_res_stage; size_t res_stage_bytes;   // flacamd_decoder_residuals_host: the device side of its copy
+	uint64_t last_samples;
 	int long_predictors;   // the stream has predictors of more than FD_REGORD taps: the kernel with room for them is used
 };
 
@@ -1096,6 +1141,7 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	if(d->d_in_stage) (void)hipFree(d->d_in_stage);
 	if(d->d_pcm_stage) (void)hipFree(d->d_pcm_stage);
 	if(d->d_subinfo) (void)hipFree(d->d_subinfo);
+	if(d->d_res_stage) (void)hipFree(d->d_res_stage);
 	free(d);
 }
 
@@ -1118,7 +1164,7 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	uint32_t ncand = 0;
 	FD_TRY(hipMemcpyAsync(&ncand, d->work.ncand, 4, hipMemcpyDeviceToHost, st));
 	FD_TRY(hipStreamSynchronize(st));
-	d->last_ncand = 0; d->last_nframes = 0; d->last_damage = 0;
+	d->last_ncand = 0; d->last_nframes = 0; d->last_damage = 0; d->last_samples = 0;
 	if(ncand == 0) {
 		if(c.tolerant) { d->last_damage = 2u; if(h_info) { h_info[0] = h_info[1] = h_info[2] = h_info[3] = 0; } return FLACAMD_OK; }
 		return FLACAMD_E_BAD_STREAM;
@@ -1147,7 +1193,37 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
 	if(res[4] & 8u) return FLACAMD_E_CAPACITY;
 	if(c.tolerant ? (res[4] & ~(uint64_t)3) != 0 : res[4] != 0) return FLACAMD_E_BAD_STREAM;
-	d->last_ncand = ncand; d->last_nframes = (uint32_t)res[0]; d->last_damage = (uint32_t)(res[4] & 3u);
+	d->last_ncand = ncand; d->last_nframes = (uint32_t)res[0]; d->last_damage = (uint32_t)(res[4] & 3u); d->last_samples = res[1];
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_residuals_device(flacamd_decoder *d, int32_t *d_out, uint64_t cap_samples, void *stream)
+{
+	if(!d || !d_out || !d->cfg.subinfo || !d->d_subinfo) return FLACAMD_E_INVALID_ARGUMENT;
+	if(d->last_samples > cap_samples) return FLACAMD_E_CAPACITY;
+	if(d->last_nframes == 0) return FLACAMD_OK;
+	FD_TRY(hipSetDevice(d->device));
+	hipLaunchKernelGGL(fd_residual_kernel, dim3(d->last_nframes * d->cfg.channels), dim3(256), 0, (hipStream_t)stream, d->cfg, d->work, d_out);
+	FD_TRY(hipGetLastError());
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_residuals_host(flacamd_decoder *d, int32_t *h_out, uint64_t cap_samples)
+{
+	if(!d || !h_out) return FLACAMD_E_INVALID_ARGUMENT;
+	const size_t need = (size_t)d->last_samples * d->cfg.channels * sizeof(int32_t);
+	if(d->last_samples > cap_samples) return FLACAMD_E_CAPACITY;
+	if(need == 0) return d->cfg.subinfo ? FLACAMD_OK : FLACAMD_E_INVALID_ARGUMENT;
+	FD_TRY(hipSetDevice(d->device));
+	if(d->res_stage_bytes < need) {
+		if(d->d_res_stage) (void)hipFree(d->d_res_stage);
+		d->d_res_stage = 0; d->res_stage_bytes = 0;
+		FD_TRY(hipMalloc(&d->d_res_stage, need));
+		d->res_stage_bytes = need;
+	}
+	const int rc = flacamd_decoder_residuals_device(d, (int32_t*)d->d_res_stage, d->last_samples, 0);
+	if(rc != FLACAMD_OK) return rc;
+	FD_TRY(hipMemcpy(h_out, d->d_res_stage, need, hipMemcpyDeviceToHost));
 	return FLACAMD_OK;
 }
 

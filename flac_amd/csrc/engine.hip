@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <unordered_map>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -222,7 +223,19 @@ extern "C" size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uin
 	return e ? (size_t)nframes * e->cfg.slot_bytes : 0;
 }
 
+static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_params *params, uint32_t max_frames);
+extern "C" void flacamd_pipe_trim(void);
+
+// Idle pipes that were parked for reuse hold device arenas and pinned slots; before an allocation failure is
+// reported they are given back and the creation is tried once more.
 extern "C" int flacamd_encoder_create(flacamd_encoder **out, int device, const flacamd_params *params, uint32_t max_frames)
+{
+	int rc = encoder_create_once(out, device, params, max_frames);
+	if(rc == FLACAMD_E_OUT_OF_MEMORY) { (void)hipGetLastError(); flacamd_pipe_trim(); rc = encoder_create_once(out, device, params, max_frames); }
+	return rc;
+}
+
+static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_params *params, uint32_t max_frames)
 {
 	if(!out || !params || max_frames == 0) return FLACAMD_E_INVALID_ARGUMENT;
 	*out = 0;
@@ -917,24 +930,45 @@ struct PipeMeta { uint32_t status, last_assignment; uint64_t total; };
 static std::mutex g_pin_lock;
 static struct { void *p; size_t bytes; } g_pin[PIN_CACHE_ENTRIES];
 static size_t g_pin_total;
+// the true size of every buffer handed out: what a buffer is cached under is never the size its caller states
+// when giving it back (flacamd_host_free is public, and a wrong size there must not turn into a short buffer later)
+static std::unordered_map<void*, size_t> g_pin_live;
+
+static void pin_cache_flush_locked()
+{
+	for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p) { (void)hipHostFree(g_pin[i].p); g_pin[i].p = 0; g_pin[i].bytes = 0; }
+	g_pin_total = 0;
+}
 
 static hipError_t pinned_alloc(void **out, size_t bytes)
 {
-	{
-		std::lock_guard<std::mutex> hold(g_pin_lock);
-		for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p && g_pin[i].bytes == bytes) { *out = g_pin[i].p; g_pin[i].p = 0; g_pin_total -= bytes; return hipSuccess; }
+	std::lock_guard<std::mutex> hold(g_pin_lock);
+	for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p && g_pin[i].bytes == bytes) {
+		*out = g_pin[i].p; g_pin[i].p = 0; g_pin_total -= bytes; g_pin_live[*out] = bytes; return hipSuccess;
 	}
-	return hipHostMalloc(out, bytes, hipHostMallocPortable);
+	hipError_t he = hipHostMalloc(out, bytes, hipHostMallocPortable);
+	if(he != hipSuccess) {   // give the idle buffers back and try once more before reporting failure
+		(void)hipGetLastError();
+		pin_cache_flush_locked();
+		he = hipHostMalloc(out, bytes, hipHostMallocPortable);
+	}
+	if(he == hipSuccess) g_pin_live[*out] = bytes;
+	return he;
 }
 
-static void pinned_free(void *p, size_t bytes)
+static void pinned_free(void *p, size_t /*stated_bytes*/)
 {
 	if(!p) return;
 	{
 		std::lock_guard<std::mutex> hold(g_pin_lock);
-		if(g_pin_total + bytes <= PIN_CACHE_BYTES) for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(!g_pin[i].p) { g_pin[i].p = p; g_pin[i].bytes = bytes; g_pin_total += bytes; return; }
+		const auto it = g_pin_live.find(p);
+		if(it != g_pin_live.end()) {
+			const size_t bytes = it->second;
+			g_pin_live.erase(it);
+			if(g_pin_total + bytes <= PIN_CACHE_BYTES) for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(!g_pin[i].p) { g_pin[i].p = p; g_pin[i].bytes = bytes; g_pin_total += bytes; return; }
+		}
 	}
-	(void)hipHostFree(p);
+	(void)hipHostFree(p);   // not cached (cache full, or not one of ours: then hipHostFree reports it and nothing else happens)
 }
 
 static void pipe_trim_parked();
@@ -942,8 +976,7 @@ extern "C" void flacamd_pipe_trim(void)
 {
 	pipe_trim_parked();
 	std::lock_guard<std::mutex> hold(g_pin_lock);
-	for(int i = 0; i < PIN_CACHE_ENTRIES; i++) if(g_pin[i].p) { (void)hipHostFree(g_pin[i].p); g_pin[i].p = 0; g_pin[i].bytes = 0; }
-	g_pin_total = 0;
+	pin_cache_flush_locked();
 }
 
 struct PipeSlot {
@@ -1026,7 +1059,16 @@ static void pipe_free(flacamd_pipe *pp)
 	free(pp->slots); free(pp->lanes); free(pp);
 }
 
+static int pipe_create_once(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth);
+
 extern "C" int flacamd_pipe_create(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth)
+{
+	int rc = pipe_create_once(out, devices, ndevices, params, batch_frames, depth);
+	if(rc == FLACAMD_E_OUT_OF_MEMORY) { (void)hipGetLastError(); flacamd_pipe_trim(); rc = pipe_create_once(out, devices, ndevices, params, batch_frames, depth); }   // parked pipes and cached slots given back first
+	return rc;
+}
+
+static int pipe_create_once(flacamd_pipe **out, const int *devices, uint32_t ndevices, const flacamd_params *params, uint32_t batch_frames, uint32_t depth)
 {
 	if(!out || !devices || ndevices == 0 || ndevices > 64 || !params || batch_frames == 0) return FLACAMD_E_INVALID_ARGUMENT;
 	*out = 0;

@@ -58,16 +58,28 @@ static const uint8_t W64_DATA[16] = { 'd','a','t','a', 0xF3,0xAC,0xD3,0x11, 0xD1
 
 /* RIFF WAVE, RF64 (a 'ds64' chunk carries the 64-bit sizes) and Wave64 (16-byte chunk ids, 64-bit sizes that count the
  * 24-byte chunk header, 8-byte alignment): get_sample_info_wave, E:202-679 */
+/* Position after a chunk body of `len` bytes and `pad` alignment bytes that starts at pos (pos <= size).  A chunk
+ * that claims to run past the end of the file leaves the position at the end: the reference seeks past the end
+ * without complaint and then finds no further chunk (E:606-660, fskip_ahead), which is what the callers then report. */
+static uint64_t skip_chunk(uint64_t pos, uint64_t size, uint64_t len, uint64_t pad)
+{
+	const uint64_t room = size - pos;
+	if(len > room || pad > room - len) return size;
+	return pos + len + pad;
+}
+
 static int parse_wave(const uint8_t *f, uint64_t size, int variant, pcm_input *in, flacamd_file_result *res)
 {
 	const int w64 = variant == FLACAMD_FILE_WAVE64, rf64 = variant == FLACAMD_FILE_RF64;
 	const unsigned idlen = w64 ? 16u : 4u, hdr = w64 ? 24u : 8u;
 	uint64_t pos = w64 ? 40 : 12, ds64_data = 0; int got_fmt = 0, got_ds64 = 0;
 	in->big_endian = 0;
-	while(pos + idlen <= size) {
+	/* pos never passes size, and every comparison against the end of the file subtracts from size instead of adding
+	 * to pos: a declared 64-bit length near 2^64 must not wrap the sum */
+	while(pos <= size && size - pos >= idlen) {
 		const uint8_t *id = f + pos;
 		uint64_t len;   /* bytes after the chunk header, as declared */
-		if(pos + hdr > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "incomplete chunk header");
+		if(size - pos < hdr) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "incomplete chunk header");
 		if(w64) {
 			len = le64(f + pos + 16);
 			pos += hdr;
@@ -83,15 +95,15 @@ static int parse_wave(const uint8_t *f, uint64_t size, int variant, pcm_input *i
 		if(rf64 && 0 == memcmp(id, "ds64", 4)) {
 			if(got_ds64) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "file has multiple 'ds64' chunks");
 			if(got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "'ds64' chunk appears after 'fmt ' or 'data' chunk");
-			if(len < 28 || pos + len > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'ds64' chunk has length = %u", (unsigned)len);
+			if(len < 28 || len > size - pos) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'ds64' chunk has length = %u", (unsigned)len);
 			ds64_data = le64(f + pos + 8);
 			got_ds64 = 1;
-			pos += len + (len & 1);
+			pos = skip_chunk(pos, size, len, len & 1);
 		}
 		else if(w64 ? 0 == memcmp(id, W64_FMT, 16) : 0 == memcmp(id, "fmt ", 4)) {
 			unsigned tag; const uint64_t body = len;
 			if(got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "file has multiple 'fmt ' chunks");
-			if(body < 16 || pos + body > size) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'fmt ' chunk has length = %u", (unsigned)body);
+			if(body < 16 || body > size - pos) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "non-standard 'fmt ' chunk has length = %u", (unsigned)body);
 			tag = le16(f + pos);
 			if(tag != 1 && tag != 65534) return fail(res, FLACAMD_E_UNSUPPORTED, "unsupported format type %u", tag);
 			in->channels = le16(f + pos + 2); in->sample_rate = le32(f + pos + 4); in->bps = le16(f + pos + 14);
@@ -117,7 +129,7 @@ static int parse_wave(const uint8_t *f, uint64_t size, int variant, pcm_input *i
 				in->channel_mask = mask;
 			}
 			got_fmt = 1;
-			pos += w64 ? ((body + 7) & ~(uint64_t)7) : body + (body & 1);
+			pos = skip_chunk(pos, size, body, w64 ? (8 - (body & 7)) & 7 : body & 1);
 		}
 		else if(w64 ? 0 == memcmp(id, W64_DATA, 16) : 0 == memcmp(id, "data", 4)) {
 			if(!got_fmt) return fail(res, FLACAMD_E_INVALID_ARGUMENT, "got 'data' chunk before 'fmt' chunk");
@@ -130,7 +142,7 @@ static int parse_wave(const uint8_t *f, uint64_t size, int variant, pcm_input *i
 			in->available_bytes = size - pos < len ? size - pos : len;
 			return 0;
 		}
-		else pos += w64 ? len : len + (len & 1); /* unknown chunk: skipped (E:606-660) */
+		else pos = skip_chunk(pos, size, len, w64 ? 0 : len & 1); /* unknown chunk: skipped (E:606-660) */
 	}
 	return fail(res, FLACAMD_E_INVALID_ARGUMENT, got_fmt ? "didn't find data chunk" : "didn't find fmt chunk");
 }
@@ -423,6 +435,9 @@ static int encode_flac_input(const uint8_t *map, uint64_t size, const char *in_p
 		total_in = ((uint64_t)(si[13] & 15u) << 32) | be32(si + 14);
 	}
 	if(total_in == 0) return fail(res, FLACAMD_E_UNSUPPORTED, "FLAC input has STREAMINFO with unknown total samples which is not supported");
+	/* the header is the file's word, not yet checked by any encoder or decoder: the rate divides sample counts below */
+	if(rate == 0 || rate > 655350) return fail(res, FLACAMD_E_UNSUPPORTED, "unsupported sample rate %u", rate);
+	if(bps < 4 || bps > 24) return fail(res, FLACAMD_E_UNSUPPORTED, "unsupported bits-per-sample %u", bps);
 	while(!last) {
 		uint32_t len; unsigned type;
 		if(pos + 4 > size) { rc = fail(res, FLACAMD_E_BAD_STREAM, "reading metadata in FLAC input"); goto done; }

@@ -13,36 +13,40 @@ static const uint32_t md5_k[64] = {
 	0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
 	0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
 	0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
-/* one 64-byte block, fully unrolled: the chain of 64 dependent steps is what bounds a single stream */
-#define MD5_F1(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
-#define MD5_F2(x, y, z) MD5_F1(z, x, y)
-#define MD5_F3(x, y, z) ((x) ^ (y) ^ (z))
-#define MD5_F4(x, y, z) ((y) ^ ((x) | ~(z)))
-#define MD5_STEP(f, w, x, y, z, in, s) ((w) += f(x, y, z) + (in), (w) = ((w) << (s) | (w) >> (32 - (s))) + (x))
+/* One 64-byte block (RFC 1321): 64 steps in four rounds of 16; step i mixes word md5_word(i) of the block with
+ * md5_k[i] into the running state through the round's boolean function and a left rotation by md5_rot(i).  The
+ * loops have constant trip counts and are unrolled by the compiler (the state rotates through a, b, c, d by
+ * renaming), which leaves the chain of 64 dependent steps that bounds a single stream. */
+static inline uint32_t md5_rotl(uint32_t v, unsigned s) { return v << s | v >> (32u - s); }
+static inline uint32_t md5_mix(unsigned round, uint32_t b, uint32_t c, uint32_t d)
+{
+	switch(round) {
+	case 0: return d ^ (b & (c ^ d));      /* b ? c : d */
+	case 1: return c ^ (d & (b ^ c));      /* d ? b : c */
+	case 2: return b ^ c ^ d;              /* parity */
+	default: return c ^ (b | ~d);
+	}
+}
 static void md5_block(md5_state *m, const uint8_t *p)
 {
+	static const uint8_t rot[4][4] = { { 7, 12, 17, 22 }, { 5, 9, 14, 20 }, { 4, 11, 16, 23 }, { 6, 10, 15, 21 } };
+	static const uint8_t first[4] = { 0, 1, 5, 0 }, stride[4] = { 1, 5, 3, 7 };   /* word of step j of round r: (first + j * stride) mod 16 */
 	uint32_t w[16], a = m->h[0], b = m->h[1], c = m->h[2], d = m->h[3];
+	unsigned r, j;
 #if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
 	memcpy(w, p, 64);
 #else
-	{ int i; for(i = 0; i < 16; i++) w[i] = (uint32_t)p[4*i] | (uint32_t)p[4*i+1] << 8 | (uint32_t)p[4*i+2] << 16 | (uint32_t)p[4*i+3] << 24; }
+	for(j = 0; j < 16; j++) w[j] = (uint32_t)p[4*j] | (uint32_t)p[4*j+1] << 8 | (uint32_t)p[4*j+2] << 16 | (uint32_t)p[4*j+3] << 24;
 #endif
-	MD5_STEP(MD5_F1, a, b, c, d, w[0] + md5_k[0], 7); MD5_STEP(MD5_F1, d, a, b, c, w[1] + md5_k[1], 12); MD5_STEP(MD5_F1, c, d, a, b, w[2] + md5_k[2], 17); MD5_STEP(MD5_F1, b, c, d, a, w[3] + md5_k[3], 22);
-	MD5_STEP(MD5_F1, a, b, c, d, w[4] + md5_k[4], 7); MD5_STEP(MD5_F1, d, a, b, c, w[5] + md5_k[5], 12); MD5_STEP(MD5_F1, c, d, a, b, w[6] + md5_k[6], 17); MD5_STEP(MD5_F1, b, c, d, a, w[7] + md5_k[7], 22);
-	MD5_STEP(MD5_F1, a, b, c, d, w[8] + md5_k[8], 7); MD5_STEP(MD5_F1, d, a, b, c, w[9] + md5_k[9], 12); MD5_STEP(MD5_F1, c, d, a, b, w[10] + md5_k[10], 17); MD5_STEP(MD5_F1, b, c, d, a, w[11] + md5_k[11], 22);
-	MD5_STEP(MD5_F1, a, b, c, d, w[12] + md5_k[12], 7); MD5_STEP(MD5_F1, d, a, b, c, w[13] + md5_k[13], 12); MD5_STEP(MD5_F1, c, d, a, b, w[14] + md5_k[14], 17); MD5_STEP(MD5_F1, b, c, d, a, w[15] + md5_k[15], 22);
-	MD5_STEP(MD5_F2, a, b, c, d, w[1] + md5_k[16], 5); MD5_STEP(MD5_F2, d, a, b, c, w[6] + md5_k[17], 9); MD5_STEP(MD5_F2, c, d, a, b, w[11] + md5_k[18], 14); MD5_STEP(MD5_F2, b, c, d, a, w[0] + md5_k[19], 20);
-	MD5_STEP(MD5_F2, a, b, c, d, w[5] + md5_k[20], 5); MD5_STEP(MD5_F2, d, a, b, c, w[10] + md5_k[21], 9); MD5_STEP(MD5_F2, c, d, a, b, w[15] + md5_k[22], 14); MD5_STEP(MD5_F2, b, c, d, a, w[4] + md5_k[23], 20);
-	MD5_STEP(MD5_F2, a, b, c, d, w[9] + md5_k[24], 5); MD5_STEP(MD5_F2, d, a, b, c, w[14] + md5_k[25], 9); MD5_STEP(MD5_F2, c, d, a, b, w[3] + md5_k[26], 14); MD5_STEP(MD5_F2, b, c, d, a, w[8] + md5_k[27], 20);
-	MD5_STEP(MD5_F2, a, b, c, d, w[13] + md5_k[28], 5); MD5_STEP(MD5_F2, d, a, b, c, w[2] + md5_k[29], 9); MD5_STEP(MD5_F2, c, d, a, b, w[7] + md5_k[30], 14); MD5_STEP(MD5_F2, b, c, d, a, w[12] + md5_k[31], 20);
-	MD5_STEP(MD5_F3, a, b, c, d, w[5] + md5_k[32], 4); MD5_STEP(MD5_F3, d, a, b, c, w[8] + md5_k[33], 11); MD5_STEP(MD5_F3, c, d, a, b, w[11] + md5_k[34], 16); MD5_STEP(MD5_F3, b, c, d, a, w[14] + md5_k[35], 23);
-	MD5_STEP(MD5_F3, a, b, c, d, w[1] + md5_k[36], 4); MD5_STEP(MD5_F3, d, a, b, c, w[4] + md5_k[37], 11); MD5_STEP(MD5_F3, c, d, a, b, w[7] + md5_k[38], 16); MD5_STEP(MD5_F3, b, c, d, a, w[10] + md5_k[39], 23);
-	MD5_STEP(MD5_F3, a, b, c, d, w[13] + md5_k[40], 4); MD5_STEP(MD5_F3, d, a, b, c, w[0] + md5_k[41], 11); MD5_STEP(MD5_F3, c, d, a, b, w[3] + md5_k[42], 16); MD5_STEP(MD5_F3, b, c, d, a, w[6] + md5_k[43], 23);
-	MD5_STEP(MD5_F3, a, b, c, d, w[9] + md5_k[44], 4); MD5_STEP(MD5_F3, d, a, b, c, w[12] + md5_k[45], 11); MD5_STEP(MD5_F3, c, d, a, b, w[15] + md5_k[46], 16); MD5_STEP(MD5_F3, b, c, d, a, w[2] + md5_k[47], 23);
-	MD5_STEP(MD5_F4, a, b, c, d, w[0] + md5_k[48], 6); MD5_STEP(MD5_F4, d, a, b, c, w[7] + md5_k[49], 10); MD5_STEP(MD5_F4, c, d, a, b, w[14] + md5_k[50], 15); MD5_STEP(MD5_F4, b, c, d, a, w[5] + md5_k[51], 21);
-	MD5_STEP(MD5_F4, a, b, c, d, w[12] + md5_k[52], 6); MD5_STEP(MD5_F4, d, a, b, c, w[3] + md5_k[53], 10); MD5_STEP(MD5_F4, c, d, a, b, w[10] + md5_k[54], 15); MD5_STEP(MD5_F4, b, c, d, a, w[1] + md5_k[55], 21);
-	MD5_STEP(MD5_F4, a, b, c, d, w[8] + md5_k[56], 6); MD5_STEP(MD5_F4, d, a, b, c, w[15] + md5_k[57], 10); MD5_STEP(MD5_F4, c, d, a, b, w[6] + md5_k[58], 15); MD5_STEP(MD5_F4, b, c, d, a, w[13] + md5_k[59], 21);
-	MD5_STEP(MD5_F4, a, b, c, d, w[4] + md5_k[60], 6); MD5_STEP(MD5_F4, d, a, b, c, w[11] + md5_k[61], 10); MD5_STEP(MD5_F4, c, d, a, b, w[2] + md5_k[62], 15); MD5_STEP(MD5_F4, b, c, d, a, w[9] + md5_k[63], 21);
+#pragma GCC unroll 4
+	for(r = 0; r < 4; r++) {
+#pragma GCC unroll 16
+		for(j = 0; j < 16; j++) {
+			const uint32_t t = a + md5_mix(r, b, c, d) + w[(first[r] + j * stride[r]) & 15u] + md5_k[16u * r + j];
+			a = d; d = c; c = b;
+			b += md5_rotl(t, rot[r][j & 3u]);
+		}
+	}
 	m->h[0] += a; m->h[1] += b; m->h[2] += c; m->h[3] += d;
 }
 static void md5_init(md5_state *m) { m->h[0] = 0x67452301; m->h[1] = 0xefcdab89; m->h[2] = 0x98badcfe; m->h[3] = 0x10325476; m->nbytes = 0; }

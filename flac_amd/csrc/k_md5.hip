@@ -215,6 +215,7 @@ extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format,
 {
 	if(!d_pcm || !h_offsets || !h_digests || nstreams == 0 || channels == 0 || channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
 	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(bits_per_sample < 1 || bits_per_sample > 32) return FLACAMD_E_INVALID_ARGUMENT;   // a sample is hashed as 1..4 bytes
 	int ndev = 0;
 	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FLACAMD_E_NO_DEVICE;
 	hipStream_t st = (hipStream_t)stream;
@@ -234,16 +235,21 @@ extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format,
 }
 
 // ---- the same without any allocation --------------------------------------------------
-// For callers that cannot call hipMalloc (code under HIP graph capture, serving loops, harnesses that forbid
-// it): the stream offsets and the digests are staged in a fixed array that is part of the code object, one copy
+// For callers that cannot call hipMalloc (tight serving loops, harnesses that forbid allocation after start-up):
+// the stream offsets and the digests are staged in a fixed array that is part of the code object, one copy
 // per GPU at its own address.  The array's name is only a host-side handle: the device address is looked up
-// once per device with hipGetSymbolAddress and that pointer is what kernels and copies receive.
+// once per device with hipGetSymbolAddress and that pointer is what kernels and copies receive.  The call
+// still copies from and to the caller's host buffers and waits for its stream, so it is not for use inside a
+// stream capture.  Calls on one GPU share the array: they are serialised here (one lock per device, held from
+// the upload of the offsets to the end of the wait), so overlapping callers wait for one another instead of
+// overwriting each other's offsets and digests.
 #define FA_MD5_STATIC_STREAMS 65536u
 #define FA_MD5_STATIC_OFF_BYTES (((size_t)FA_MD5_STATIC_STREAMS + 1u) * 8u + 248u)   // the digests start 256-byte aligned
 static __device__ __align__(256) unsigned char scratch[FA_MD5_STATIC_OFF_BYTES + (size_t)FA_MD5_STATIC_STREAMS * 16u];
 
 #define FA_MD5_MAX_DEVICES 64
 static std::mutex g_scratch_lock;
+static std::mutex g_scratch_busy[FA_MD5_MAX_DEVICES];   // held by the call that is using the device's array
 static unsigned char *g_scratch_ptr[FA_MD5_MAX_DEVICES];
 
 // device address of this GPU's copy of `scratch` (the device must be current); NULL on failure
@@ -265,6 +271,7 @@ extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_
 {
 	if(!d_pcm || !h_offsets || !h_digests || nstreams == 0 || channels == 0 || channels > FLACAMD_MAX_CHANNELS) return FLACAMD_E_INVALID_ARGUMENT;
 	if(pcm_format != FLACAMD_PCM_S32 && pcm_format != FLACAMD_PCM_S16) return FLACAMD_E_INVALID_ARGUMENT;
+	if(bits_per_sample < 1 || bits_per_sample > 32) return FLACAMD_E_INVALID_ARGUMENT;
 	if(nstreams > FA_MD5_STATIC_STREAMS) return FLACAMD_E_CAPACITY;   // more streams than the fixed array stages: split the batch, or use flacamd_md5_device
 	int ndev = 0;
 	if(hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= FA_MD5_MAX_DEVICES) return FLACAMD_E_NO_DEVICE;
@@ -274,6 +281,7 @@ extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_
 	if(!base) return FLACAMD_E_DEVICE;
 	uint64_t *d_off = (uint64_t*)base;
 	uint8_t *d_dig = base + FA_MD5_STATIC_OFF_BYTES;
+	std::lock_guard<std::mutex> busy(g_scratch_busy[device]);
 	// nothing in the array has to start at zero: the kernel reads offsets[0..nstreams] and writes every byte of
 	// digests[0..nstreams), both overwritten here, and nothing beyond them is copied out
 	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
@@ -294,7 +302,7 @@ extern "C" void fa_launch_md5(const void *d_pcm, uint32_t pcm_format, uint32_t c
 // ---- the digests of several clip batches in one launch
 namespace {
 std::mutex g_md5_groups_lock;
-struct Md5GroupsBuf { void *h; void *d; size_t cap; };
+struct Md5GroupsBuf { void *h; void *d; size_t cap; hipEvent_t done; bool pending; };   // done: recorded behind the last launch that reads h and d
 Md5GroupsBuf g_md5_groups_buf[64];
 }
 
@@ -315,6 +323,10 @@ extern "C" int flacamd_md5_groups_device(int device, uint32_t ngroups, const fla
 	std::lock_guard<std::mutex> hold(g_md5_groups_lock);
 	Md5GroupsBuf &b = g_md5_groups_buf[device];
 	const size_t bytes = total * sizeof(FaMd5Rec);
+	// the previous call's copy reads b.h and its kernel reads b.d when the stream gets to them, not when the call
+	// returned: wait for both before the staging buffers are written again or freed
+	if(b.pending) { if(hipEventSynchronize(b.done) != hipSuccess) return FLACAMD_E_DEVICE; b.pending = false; }
+	if(!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { b.done = 0; return FLACAMD_E_DEVICE; }
 	if(b.cap < bytes) {   // grow-only staging: none of this on the steady path
 		if(b.h) (void)hipHostFree(b.h);
 		if(b.d) (void)hipFree(b.d);
@@ -339,5 +351,8 @@ extern "C" int flacamd_md5_groups_device(int device, uint32_t ngroups, const fla
 	hipStream_t st = (hipStream_t)stream;
 	if(hipMemcpyAsync(b.d, b.h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
 	hipLaunchKernelGGL(fa_md5_multi_kernel, dim3((uint32_t)(total / 64u)), dim3(64), 0, st, (const FaMd5Rec*)b.d, (uint32_t)total);
-	return hipGetLastError() == hipSuccess ? FLACAMD_OK : FLACAMD_E_DEVICE;
+	if(hipGetLastError() != hipSuccess) return FLACAMD_E_DEVICE;
+	if(hipEventRecord(b.done, st) == hipSuccess) b.pending = true;
+	else if(hipStreamSynchronize(st) != hipSuccess) return FLACAMD_E_DEVICE;
+	return FLACAMD_OK;
 }

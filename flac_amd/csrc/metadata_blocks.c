@@ -75,6 +75,26 @@ FLAC__bool FLAC__format_vorbiscomment_entry_is_legal(const FLAC__byte *entry, un
 	return s == end;
 }
 
+/* format.c:363-370: every character of a tag's name printable ASCII other than '=' and '~' */
+FLAC__bool FLAC__format_vorbiscomment_entry_name_is_legal(const char *name)
+{
+	for(; *name; name++) if(*name < 0x20 || *name == '=' || *name > 0x7D) return 0;
+	return 1;
+}
+
+/* format.c:372-394: the value is whole well-formed UTF-8 sequences; length (unsigned)(-1) means NUL-terminated */
+FLAC__bool FLAC__format_vorbiscomment_entry_value_is_legal(const FLAC__byte *value, unsigned length)
+{
+	const int terminated = length == (unsigned)(-1);
+	const FLAC__byte *end = terminated ? 0 : value + length;
+	while(terminated ? *value != 0 : value < end) {
+		unsigned n = utf8_sequence(value);
+		if(n == 0) return 0;
+		value += n;
+	}
+	return terminated || value == end;
+}
+
 /* format.c:422-498 */
 FLAC__bool FLAC__format_cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet *cs, FLAC__bool cdda, const char **violation)
 {

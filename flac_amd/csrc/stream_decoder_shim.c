@@ -61,7 +61,8 @@ struct FLAC__StreamDecoder {
 	 * the reference decodes them with the frame's own parameters (:2002-2145); here a second device decoder built for
 	 * those parameters takes the frame, and the event carries its samples */
 	flacamd_decoder *alt_eng; unsigned alt_ch, alt_bps, alt_bs; size_t alt_bytes;
-	struct alt_frame { int32_t *pcm; flacamd_subframe_info sub[8]; unsigned ch, bps; } **f_alt;
+	struct alt_frame { int32_t *pcm, *res; flacamd_subframe_info sub[8]; unsigned ch, bps; } **f_alt;
+	int32_t *res; int want_res;   /* the batch's residuals as the stream carried them (FLAC__Subframe_*::residual), page-locked like pcm */
 	size_t planar_cap, pcm_bytes;
 	int search_warned;               /* LOST_SYNC already reported for the sync search in progress (frame_sync_'s `first`) */
 	FLAC__uint64 decode_pos;          /* absolute offset just past the last frame handed out */
@@ -77,10 +78,10 @@ struct FLAC__StreamDecoder {
 
 static void dec_defaults(FLAC__StreamDecoder *d) /* set_defaults_, :1247-1268 */
 {
-	const int device = d->device; const unsigned batch = d->batch_frames;
+	const int device = d->device, want_res = d->want_res; const unsigned batch = d->batch_frames;
 	free(d->app_ids);
 	memset(d, 0, sizeof *d);
-	d->device = device; d->batch_frames = batch ? batch : 2048u;
+	d->device = device; d->batch_frames = batch ? batch : 2048u; d->want_res = want_res;
 	d->state = FLAC__STREAM_DECODER_UNINITIALIZED;
 	d->respond[FLAC__METADATA_TYPE_STREAMINFO] = 1; d->md5_checking = 0;
 }
@@ -88,14 +89,20 @@ static void dec_defaults(FLAC__StreamDecoder *d) /* set_defaults_, :1247-1268 */
 FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
 {
 	FLAC__StreamDecoder *d = (FLAC__StreamDecoder*)calloc(1, sizeof *d);
-	if(d) dec_defaults(d);
+	if(d) {
+		const char *env = getenv("FLACAMD_DECODER_RESIDUALS");   /* for clients that cannot call the setter: "0" turns the residual pass off */
+		dec_defaults(d);
+		d->want_res = !(env && env[0] == '0' && env[1] == 0);
+	}
 	return d;
 }
+
+static void alt_free(struct alt_frame *a) { if(a) { free(a->pcm); free(a->res); free(a); } }
 
 static void dec_free(FLAC__StreamDecoder *d)
 {
 	if(d->eng) { flacamd_decoder_destroy(d->eng); d->eng = 0; }
-	flacamd_host_free(d->in, d->in_cap); d->in = 0; flacamd_host_free(d->pcm, d->pcm_bytes); d->pcm = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
+	flacamd_host_free(d->in, d->in_cap); d->in = 0; flacamd_host_free(d->pcm, d->pcm_bytes); d->pcm = 0; flacamd_host_free(d->res, d->pcm_bytes); d->res = 0; free(d->f_off); d->f_off = 0; free(d->f_num); d->f_num = 0; free(d->f_end); d->f_end = 0;
 	free(d->f_bs); d->f_bs = 0; free(d->f_asg); d->f_asg = 0; free(d->planar); d->planar = 0; free(d->md5_scratch); d->md5_scratch = 0;
 	free(d->f_sn); d->f_sn = 0; free(d->f_kind); d->f_kind = 0; free(d->c_pos); d->c_pos = 0; free(d->c_end); d->c_end = 0; free(d->c_num); d->c_num = 0;
 	free(d->c_off); d->c_off = 0; free(d->c_info); d->c_info = 0; free(d->c_bs); d->c_bs = 0;
@@ -110,6 +117,7 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 {
 	if(!d) return;
 	(void)FLAC__stream_decoder_finish(d);
+	if(d->file && d->file != stdin) fclose(d->file);   /* left by an init_ogg_* call that was refused */
 	free(d->app_ids);
 	free(d);
 }
@@ -117,6 +125,7 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 #define DEC_SETTER(name, type, stmt) FLAC__bool name(FLAC__StreamDecoder *d, type value) { if(!d || d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return 0; stmt; return 1; }
 DEC_SETTER(FLAC__stream_decoder_set_md5_checking, FLAC__bool, d->md5_checking = value)
 DEC_SETTER(flacamd_stream_decoder_set_device, int, if(value < 0) return 0; d->device = value)
+DEC_SETTER(flacamd_stream_decoder_set_residuals, FLAC__bool, d->want_res = value ? 1 : 0)
 DEC_SETTER(flacamd_stream_decoder_set_batch_frames, unsigned, if(value == 0) return 0; d->batch_frames = value)
 /* the metadata filter (:762-877) */
 #define UNINIT(d) ((d) && (d)->state == FLAC__STREAM_DECODER_UNINITIALIZED)
@@ -262,6 +271,42 @@ FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder
 	return st;
 }
 
+/* The Ogg inits as a library built without Ogg transport has them (:517-700 over the `#if !FLAC__HAS_OGG` exit of
+ * init_stream_internal_, :394-399): the checks ahead of that exit, then UNSUPPORTED_CONTAINER.  A file that
+ * init_ogg_file opened stays with the object, as in the reference, and is closed by finish() or delete(). */
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_stream(FLAC__StreamDecoder *d, FLAC__StreamDecoderReadCallback rcb, FLAC__StreamDecoderSeekCallback scb,
+	FLAC__StreamDecoderTellCallback tcb, FLAC__StreamDecoderLengthCallback lcb, FLAC__StreamDecoderEofCallback ecb, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	(void)rcb; (void)scb; (void)tcb; (void)lcb; (void)ecb; (void)wcb; (void)mcb; (void)errcb; (void)client_data;
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	return FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_FILE(FLAC__StreamDecoder *d, FILE *file, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	(void)mcb; (void)client_data;
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!wcb || !errcb) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+	d->file = file;
+	return FLAC__STREAM_DECODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_file(FLAC__StreamDecoder *d, const char *filename, FLAC__StreamDecoderWriteCallback wcb,
+	FLAC__StreamDecoderMetadataCallback mcb, FLAC__StreamDecoderErrorCallback errcb, void *client_data)
+{
+	FILE *f;
+	if(d->state != FLAC__STREAM_DECODER_UNINITIALIZED) return FLAC__STREAM_DECODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!wcb || !errcb) return FLAC__STREAM_DECODER_INIT_STATUS_INVALID_CALLBACKS;
+	f = filename ? fopen(filename, "rb") : stdin;
+	if(!f) return FLAC__STREAM_DECODER_INIT_STATUS_ERROR_OPENING_FILE;
+	return FLAC__stream_decoder_init_ogg_FILE(d, f, wcb, mcb, errcb, client_data);
+}
+
+/* :736-751 without libogg */
+FLAC__bool FLAC__stream_decoder_set_ogg_serial_number(FLAC__StreamDecoder *d, long value) { (void)d; (void)value; return 0; }
+
 /* ---- input: make at least `need` unread bytes available (fewer at end of stream) */
 static FLAC__bool fill_range(FLAC__StreamDecoder *d, size_t least, size_t want);
 static FLAC__bool fill(FLAC__StreamDecoder *d, size_t need) { return fill_range(d, need, need); }
@@ -370,6 +415,7 @@ static FLAC__bool start_frames(FLAC__StreamDecoder *d)
 		if(!d->sub || !d->f_cand || !d->frame_cand || !d->f_alt) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->pcm_bytes = sizeof(int32_t) * d->pcm_cap * si->channels;
 		d->pcm = (int32_t*)flacamd_host_alloc(d->pcm_bytes);   /* page-locked: a batch's samples come back at bus speed */
+		if(d->want_res && !(d->res = (int32_t*)flacamd_host_alloc(d->pcm_bytes))) { d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->f_off = (uint64_t*)malloc(8u * d->ev_cap); d->f_num = (uint64_t*)malloc(8u * d->ev_cap); d->f_end = (uint64_t*)malloc(8u * d->ev_cap); d->f_sn = (uint64_t*)malloc(8u * d->ev_cap);
 		d->f_bs = (uint32_t*)malloc(4u * d->ev_cap); d->f_asg = (uint32_t*)malloc(4u * d->ev_cap); d->f_kind = (uint8_t*)malloc(d->ev_cap);
 		d->c_pos = (uint64_t*)malloc(8u * d->eng_frames); d->c_end = (uint64_t*)malloc(8u * d->eng_frames); d->c_num = (uint64_t*)malloc(8u * d->eng_frames); d->c_off = (uint64_t*)malloc(8u * d->eng_frames);
@@ -557,16 +603,18 @@ static int decode_alt_frame(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, 
 		break;
 	}
 	if(rc == FLACAMD_OK) rc = flacamd_decoder_candidate_table(d->alt_eng, 8, &nc, c_pos, c_end, c_info, c_bs, c_num, c_off);
-	if(rc != FLACAMD_OK || nc == 0 || c_pos[0] != 0) { free(af->pcm); free(af); return -1; }
+	if(rc != FLACAMD_OK || nc == 0 || c_pos[0] != 0) { alt_free(af); return -1; }
 	{
 		flacamd_subframe_info recs[8 * 8];
 		if(flacamd_decoder_subframe_info(d->alt_eng, 8, recs, 0, 0) == FLACAMD_OK) memcpy(af->sub, recs, sizeof(flacamd_subframe_info) * hh->channels);
+		if(d->want_res && (c_info[0] & 1u) && c_off[0] == 0 && (af->res = (int32_t*)calloc((size_t)hh->blocksize * hh->channels, sizeof(int32_t)))
+			&& flacamd_decoder_residuals_host(d->alt_eng, af->res, hh->blocksize) != FLACAMD_OK) { free(af->res); af->res = 0; }
 	}
 	sn = variable ? hh->number : hh->number * (uint64_t)si->min_blocksize;
 	*end = s + (size_t)c_end[0];
 	if(!(c_info[0] & 1u)) {
 		const uint32_t ex = (c_info[0] >> 8) & 15u;
-		free(af->pcm); free(af);
+		alt_free(af);
 		if(ex == 6u) return 0;
 		push_event(d, EV_ERROR, ex == 4u ? FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM : FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC, 0, 0, 0, *end);
 		return 1;
@@ -665,7 +713,7 @@ static size_t walk_damaged(FLAC__StreamDecoder *d, const uint8_t *b, size_t n, i
 static void drop_events(FLAC__StreamDecoder *d)
 {
 	unsigned k;
-	for(k = 0; d->f_alt && k < d->q_n; k++) if(d->f_alt[k]) { free(d->f_alt[k]->pcm); free(d->f_alt[k]); d->f_alt[k] = 0; }
+	for(k = 0; d->f_alt && k < d->q_n; k++) if(d->f_alt[k]) { alt_free(d->f_alt[k]); d->f_alt[k] = 0; }
 	d->q_n = d->q_i = 0;
 }
 
@@ -702,6 +750,7 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 		if(rc != FLACAMD_OK) { d->state = (rc == FLACAMD_E_OUT_OF_MEMORY) ? FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_DECODER_ABORTED; return 0; }
 		d->batch_base = d->in_base + d->in_pos; d->batch_in_off = d->in_pos;
 		if(flacamd_decoder_subframe_info(d->eng, d->eng_frames, d->sub, d->frame_cand, d->eng_frames) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+		if(d->res && flacamd_decoder_residuals_host(d->eng, d->res, d->pcm_cap) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
 		if(flacamd_decoder_damage(d->eng) == 0) {
 			const uint8_t *b = d->in + d->in_pos;
 			if(flacamd_decoder_frame_table(d->eng, (uint32_t)info[0], d->f_off, d->f_bs, d->f_num, d->f_asg, d->c_pos, d->f_end) != FLACAMD_OK) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
@@ -737,7 +786,7 @@ static FLAC__bool decode_batch(FLAC__StreamDecoder *d)
 }
 
 /* the sample rate out of the frame's own header bytes, and the subframe records of its candidate */
-static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const uint8_t *fb, size_t flen, const flacamd_subframe_info *recs)
+static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const uint8_t *fb, size_t flen, const flacamd_subframe_info *recs, const int32_t *res)
 {
 	static const unsigned rates[12] = { 0, 88200, 176400, 192000, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000 };
 	const unsigned ch = frame->header.channels; unsigned c;
@@ -757,13 +806,14 @@ static void fill_frame_details(FLAC__StreamDecoder *d, FLAC__Frame *frame, const
 		FLAC__EntropyCodingMethod *ecm = 0;
 		sf->type = (FLAC__SubframeType)type; sf->wasted_bits = (rec->head >> 8) & 31u;
 		if(type == FLAC__SUBFRAME_TYPE_CONSTANT) sf->data.constant.value = rec->value;
+		else if(type == FLAC__SUBFRAME_TYPE_VERBATIM) sf->data.verbatim.data = res ? res + (size_t)c * frame->header.blocksize : 0;
 		else if(type == FLAC__SUBFRAME_TYPE_FIXED) {
-			sf->data.fixed.order = order; sf->data.fixed.residual = 0; ecm = &sf->data.fixed.entropy_coding_method;
+			sf->data.fixed.order = order; sf->data.fixed.residual = res ? res + (size_t)c * frame->header.blocksize : 0; ecm = &sf->data.fixed.entropy_coding_method;
 			for(i = 0; i < order && i < FLAC__MAX_FIXED_ORDER; i++) sf->data.fixed.warmup[i] = rec->warmup[i];
 		}
 		else if(type == FLAC__SUBFRAME_TYPE_LPC) {
 			const unsigned lv = (rec->head >> 23) & 31u;
-			sf->data.lpc.order = order; sf->data.lpc.residual = 0; ecm = &sf->data.lpc.entropy_coding_method;
+			sf->data.lpc.order = order; sf->data.lpc.residual = res ? res + (size_t)c * frame->header.blocksize : 0; ecm = &sf->data.lpc.entropy_coding_method;
 			sf->data.lpc.qlp_coeff_precision = (rec->head >> 13) & 31u;
 			sf->data.lpc.quantization_level = (lv & 16u) ? (int)lv - 32 : (int)lv;
 			for(i = 0; i < order && i < FLAC__MAX_LPC_ORDER; i++) { sf->data.lpc.qlp_coeff[i] = rec->q[i]; sf->data.lpc.warmup[i] = rec->warmup[i]; }
@@ -813,7 +863,7 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	else src = kind == EV_FRAME ? d->pcm + d->f_off[r] * ch : 0;
 	if((size_t)n * ch > d->planar_cap) { /* longer than the stream's maximum says: the reference reallocates its output too (:2012) */
 		int32_t *np = (int32_t*)realloc(d->planar, sizeof(int32_t) * (size_t)n * ch);
-		if(!np) { if(alt) { free(alt->pcm); free(alt); } d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
+		if(!np) { if(alt) { alt_free(alt); } d->state = FLAC__STREAM_DECODER_MEMORY_ALLOCATION_ERROR; return 0; }
 		d->planar = np; d->planar_cap = (size_t)n * ch;
 	}
 	if(d->f_sn[r] != ~(uint64_t)0) d->samples_decoded = d->f_sn[r]; /* :2135: the header's number, not a running count */
@@ -824,7 +874,10 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	frame.header.number.sample_number = d->samples_decoded; /* frame number x fixed blocksize for the streams this decoder takes (:2422-2445) */
 	{ /* what read_frame_header_ / read_subframe_* leave in the frame (:2147-2454, :2456-2719) */
 		const uint8_t *fb = d->in + d->batch_in_off + d->f_num[r]; const size_t flen = (size_t)(d->f_end[r] - d->f_num[r]);
-		fill_frame_details(d, &frame, fb, flen, alt ? alt->sub : &d->sub[(size_t)d->f_cand[r] * ch]);
+		/* residuals: the frame's rows of the batch, the frame's own for one decoded by itself; a frame that is handed out
+		 * zeroed (CRC mismatch) points at zeros, as any valid memory is as good as what the reference leaves there */
+		const int32_t *res = !d->want_res ? 0 : alt ? (alt->res ? alt->res : d->planar) : (src && d->res) ? d->res + d->f_off[r] * ch : d->planar;
+		fill_frame_details(d, &frame, fb, flen, alt ? alt->sub : &d->sub[(size_t)d->f_cand[r] * ch], res);
 	}
 	d->last = frame.header;
 	if(d->do_md5 && deliver) {
@@ -837,13 +890,13 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 	}
 	if(d->is_seeking) { /* :2920-2956: drop frames before the target, trim the one that holds it */
 		const FLAC__uint64 first = d->samples_decoded;
-		if(d->target_sample >= first + n) { d->samples_decoded += n; if(alt) { free(alt->pcm); free(alt); } return 1; }
+		if(d->target_sample >= first + n) { d->samples_decoded += n; if(alt) { alt_free(alt); } return 1; }
 		skip = (unsigned)(d->target_sample - first);
 		d->is_seeking = 0;
 		frame.header.blocksize = n - skip; frame.header.number.sample_number = first + skip;
 	}
 	d->samples_decoded += n;
-	if(!deliver) { if(alt) { free(alt->pcm); free(alt); } return 1; }
+	if(!deliver) { if(alt) { alt_free(alt); } return 1; }
 	for(c = 0; c < ch; c++) {
 		int32_t *dst = d->planar + (size_t)c * n;
 		if(src && !alt) { bufs[c] = src + (size_t)c * n + skip; continue; }   /* the batch came back frame by frame, channel by channel: handed on as it lies */
@@ -851,9 +904,15 @@ static FLAC__bool next_frame(FLAC__StreamDecoder *d, int deliver)
 		else memset(dst, 0, sizeof(int32_t) * n);
 		bufs[c] = dst;
 	}
-	if(alt) { free(alt->pcm); free(alt); }
-	for(c = 0; c < ch; c++) if(frame.subframes[c].type == FLAC__SUBFRAME_TYPE_VERBATIM) frame.subframes[c].data.verbatim.data = bufs[c];
-	if(d->write_cb(d, &frame, bufs, d->client_data) != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_ABORTED; return 0; }
+	/* without the residual pass a verbatim subframe points at the channel's output samples (the coded ones, unless the
+	 * subframe has wasted bits or the channel was decorrelated) */
+	for(c = 0; c < ch; c++) if(frame.subframes[c].type == FLAC__SUBFRAME_TYPE_VERBATIM && !frame.subframes[c].data.verbatim.data) frame.subframes[c].data.verbatim.data = bufs[c];
+	{
+		const FLAC__StreamDecoderWriteStatus ws = d->write_cb(d, &frame, bufs, d->client_data);
+		alt_free(alt);
+		/* :2138-2141: read_frame_ returns false and leaves the state it had while reading the frame */
+		if(ws != FLAC__STREAM_DECODER_WRITE_STATUS_CONTINUE) { d->state = FLAC__STREAM_DECODER_READ_FRAME; return 0; }
+	}
 	return 1;
 }
 

@@ -14,7 +14,7 @@
 #include <string.h>
 #include <sys/types.h>
 
-#define VENDOR_STRING "reference libFLAC 1.2.1 20070917" /* format.c:56-63: decoders and tools compare it */
+#define VENDOR_STRING FLAC__VENDOR_STRING /* format_tables.c */
 
 const char * const FLAC__StreamEncoderStateString[] = { /* :458-468 */
 	"FLAC__STREAM_ENCODER_OK", "FLAC__STREAM_ENCODER_UNINITIALIZED", "FLAC__STREAM_ENCODER_OGG_ERROR",
@@ -32,6 +32,13 @@ const char * const FLAC__StreamEncoderInitStatusString[] = { /* :470-485 */
 
 #include "host_md5.h"
 #include "metadata_blocks.h"
+
+/* a hint to the core that this is a spin-wait; a plain compiler barrier where the architecture has no such hint */
+#if defined(__x86_64__) || defined(__i386__)
+#define cpu_relax() __builtin_ia32_pause()
+#else
+#define cpu_relax() __asm__ __volatile__("" ::: "memory")
+#endif
 
 /* ---- the object */
 struct FLAC__StreamEncoder {
@@ -254,6 +261,7 @@ FLAC__bool FLAC__stream_encoder_set_apodization(FLAC__StreamEncoder *e, const ch
 GETTER(get_state, FLAC__StreamEncoderState, e->state)
 GETTER(get_verify, FLAC__bool, e->verify)
 GETTER(get_streamable_subset, FLAC__bool, e->streamable_subset)
+GETTER(get_do_md5, FLAC__bool, e->do_md5)
 GETTER(get_channels, unsigned, e->p.channels)
 GETTER(get_bits_per_sample, unsigned, e->p.bits_per_sample)
 GETTER(get_sample_rate, unsigned, e->p.sample_rate)
@@ -522,6 +530,39 @@ FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder
 	return FLAC__stream_encoder_init_FILE(e, f, pcb, client_data);
 }
 
+/* The Ogg inits as a library built without Ogg transport has them (:1156-1308 over the `#if !FLAC__HAS_OGG`
+ * exit of init_stream_internal_, :659-662): every check that comes before that exit runs - and init_ogg_file has
+ * by then created or truncated the file, whose FILE stays with the object - and the answer is
+ * UNSUPPORTED_CONTAINER with the object still uninitialized. */
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *e, FLAC__StreamEncoderReadCallback rcb, FLAC__StreamEncoderWriteCallback wcb,
+	FLAC__StreamEncoderSeekCallback scb, FLAC__StreamEncoderTellCallback tcb, FLAC__StreamEncoderMetadataCallback mcb, void *client_data)
+{
+	(void)rcb; (void)wcb; (void)scb; (void)tcb; (void)mcb; (void)client_data;
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_FILE(FLAC__StreamEncoder *e, FILE *file, FLAC__StreamEncoderProgressCallback pcb, void *client_data)
+{
+	(void)client_data;
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	if(!file) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	e->file = file; e->progress_cb = pcb; e->bytes_written = 0; e->samples_written = 0; e->frames_written = 0;
+	return FLAC__STREAM_ENCODER_INIT_STATUS_UNSUPPORTED_CONTAINER;
+}
+
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_file(FLAC__StreamEncoder *e, const char *filename, FLAC__StreamEncoderProgressCallback pcb, void *client_data)
+{
+	FILE *f;
+	if(e->state != FLAC__STREAM_ENCODER_UNINITIALIZED) return FLAC__STREAM_ENCODER_INIT_STATUS_ALREADY_INITIALIZED;
+	f = filename ? fopen(filename, "w+b") : stdout;
+	if(!f) { e->state = FLAC__STREAM_ENCODER_IO_ERROR; return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR; }
+	return FLAC__stream_encoder_init_ogg_FILE(e, f, pcb, client_data);
+}
+
+/* :1378-1393 without libogg */
+FLAC__bool FLAC__stream_encoder_set_ogg_serial_number(FLAC__StreamEncoder *e, long value) { (void)e; (void)value; return 0; }
+
 /* sample i (interleaved index) of a batch's PCM, which is int16 or int32 */
 static int32_t pcm_at(const FLAC__StreamEncoder *e, const void *pcm, size_t i) { return e->fmt16 ? (int32_t)((const int16_t*)pcm)[i] : ((const int32_t*)pcm)[i]; }
 
@@ -744,7 +785,7 @@ static void *fill_worker(void *argp)
 		{
 			int spin;
 			pthread_mutex_unlock(&pl->lock);
-			for(spin = 0; spin < 4000 && __atomic_load_n(&pl->generation, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&pl->quit, __ATOMIC_ACQUIRE); spin++) __builtin_ia32_pause();
+			for(spin = 0; spin < 4000 && __atomic_load_n(&pl->generation, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&pl->quit, __ATOMIC_ACQUIRE); spin++) cpu_relax();
 			pthread_mutex_lock(&pl->lock);
 		}
 	}

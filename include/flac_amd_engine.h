@@ -171,7 +171,8 @@ int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm, int pcm_f
 /* The digests of several clip batches in ONE pass: every clip of every group is a lane of the same kernel launch, so the
  * whole hash takes as long as the longest clip (a digest is a serial chain, md5.c:216-420) instead of that once per
  * group.  d_digests of group g receives nclips x 16 bytes (device memory).  Asynchronous on `stream`; the tables are
- * staged in buffers that belong to the device (calls for one device must not overlap).  Hand the result to the next
+ * staged in buffers that belong to the device, and a call first waits until the previous call's work on that device
+ * has passed its launch (an event recorded behind it), so calls may follow one another on any streams.  Hand the result to the next
  * flacamd_encode_clips_device call of a group's encoder with flacamd_encoder_use_digests. */
 typedef struct {
 	const void *d_pcm; int pcm_format; uint32_t channels, bits_per_sample, nclips;
@@ -255,12 +256,14 @@ int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t c
 	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests /* [nstreams][16] */, void *stream);
 
 /* flacamd_md5_device without any allocation.  No counterpart in the reference: it is for callers that
- * cannot allocate device memory - code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  Same arguments and results as flacamd_md5_device; the stream offsets and the digests are staged
- * in a fixed array inside the library (one copy per GPU, about 1.5 MiB, held until the process ends), so
- * nstreams is limited to flacamd_md5_device_static_max_streams() = 65536 (FLACAMD_E_CAPACITY beyond that)
- * and the call makes no hipMalloc / hipFree.  All calls on one GPU share that array: calls that overlap on
- * the same GPU race, serialise them. */
+ * cannot allocate device memory - tight serving loops, harnesses that forbid hipMalloc after start-up.  Same
+ * arguments and results as flacamd_md5_device; the stream offsets and the digests are staged in a fixed array
+ * inside the library (one copy per GPU, about 1.5 MiB, held until the process ends), so nstreams is limited to
+ * flacamd_md5_device_static_max_streams() = 65536 (FLACAMD_E_CAPACITY beyond that) and the call makes no
+ * hipMalloc / hipFree.  Like flacamd_md5_device it copies from and to the caller's host buffers and waits for
+ * `stream` before it returns, so it cannot be recorded into a stream capture.  All calls on one GPU share that
+ * array; the library serialises them (a call waits while another one on the same GPU is between its upload and the
+ * end of its wait).  bits_per_sample outside 1..32: FLACAMD_E_INVALID_ARGUMENT (both entry points). */
 int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
 	const uint64_t *h_offsets, uint32_t nstreams, uint8_t *h_digests /* [nstreams][16] */, void *stream);
 uint32_t flacamd_md5_device_static_max_streams(void);
@@ -317,6 +320,7 @@ int flacamd_decoder_candidate_table(flacamd_decoder *d, uint32_t max_entries, ui
  *   head: [1:0] type (0 constant, 1 verbatim, 2 fixed, 3 lpc)  [7:2] order  [12:8] wasted bits
  *         [17:13] coefficient precision (lpc)  [18] residual coding method (0 RICE, 1 RICE2)  [22:19] partition order
  *         [27:23] quantisation level as coded (5-bit two's complement)
+ *         [28] the prediction was summed in 64 bits (stream_decoder.c:2682-2692)
  *   value: the sample of a constant subframe (before the wasted-bits shift)
  *   rice[i]: parameter of partition i, or 0x80 | raw_bits for an escaped partition; the first FLACAMD_SUBINFO_PARTS
  *         partitions are recorded (partition orders up to 8, the streamable subset's limit) */
@@ -331,6 +335,16 @@ int flacamd_decoder_set_subframe_info(flacamd_decoder *d, int on);
 /* The records of the last decode, by candidate (as in flacamd_decoder_candidate_table): h_records[candidate * channels
  * + channel].  h_frame_candidate (may be NULL) receives, per accepted frame in stream order, its candidate index. */
 int flacamd_decoder_subframe_info(flacamd_decoder *d, uint32_t max_candidates, flacamd_subframe_info *h_records, uint32_t *h_frame_candidate, uint32_t max_frames);
+
+/* The residuals the stream carried, for the frames of the last decode (subframe info must be on): what the reference
+ * hands a client as FLAC__Subframe_Fixed::residual / FLAC__Subframe_LPC::residual and, for a verbatim subframe, as
+ * FLAC__Subframe_Verbatim::data (include/FLAC/format.h:283-352; read_residual_partitioned_rice_ stream_decoder.c:2721-2777).
+ * Layout of FLACAMD_PCM_S32_FRAMES: frame after frame, within a frame channel after channel, `blocksize` entries per
+ * channel of which the first blocksize - order are the subframe's residuals (rows of constant subframes are not written).
+ * One pass over the restored signal, parallel in the sample index.  The device variant is asynchronous on `stream`
+ * (the one the decode ran on, or one ordered after it). */
+int flacamd_decoder_residuals_device(flacamd_decoder *d, int32_t *d_out, uint64_t cap_samples, void *stream);
+int flacamd_decoder_residuals_host(flacamd_decoder *d, int32_t *h_out, uint64_t cap_samples);
 
 /* "fLaC" + STREAMINFO + the empty VORBIS_COMMENT with the reference's vendor string, as the reference
  * leaves them in a finished file (stream_encoder.c:1034-1106 written at init, :2521-2620 patched at

@@ -11,8 +11,10 @@
  * (when a batch fills, or at finish()).
  *
  * Verify mode decodes every batch on the device before its frames are written and compares
- * the result with the queued input.  Not provided (calls fail, nothing is silently ignored):
- * Ogg transport (init_ogg_*).  set_do_escape_coding and
+ * the result with the queued input.  Ogg transport is not provided: the init_ogg_* functions
+ * and set_ogg_serial_number are exported and behave like the reference built without libogg
+ * (..._INIT_STATUS_UNSUPPORTED_CONTAINER, stream_encoder.c:659-662; false, :1378-1393), and
+ * FLAC_API_SUPPORTS_OGG_FLAC reads 0.  set_do_escape_coding and
  * set_rice_parameter_search_dist are accepted and have no effect, exactly as in the
  * reference (stream_encoder.c:1635-1649, :1684-1698).
  */
@@ -35,6 +37,38 @@ typedef uint8_t FLAC__uint8;
 typedef uint16_t FLAC__uint16;
 typedef int16_t FLAC__int16;
 typedef int64_t FLAC__int64;
+
+/* include/FLAC/export.h:58-83 */
+#define FLAC_API_VERSION_CURRENT 10
+#define FLAC_API_VERSION_REVISION 0
+#define FLAC_API_VERSION_AGE 2
+extern int FLAC_API_SUPPORTS_OGG_FLAC;   /* 0 */
+
+/* the format's limits, include/FLAC/format.h:92-181 */
+#define FLAC__MAX_METADATA_TYPE_CODE (126u)
+#define FLAC__MIN_BLOCK_SIZE (16u)
+#define FLAC__MAX_BLOCK_SIZE (65535u)
+#define FLAC__SUBSET_MAX_BLOCK_SIZE_48000HZ (4608u)
+#define FLAC__MAX_CHANNELS (8u)
+#define FLAC__MIN_BITS_PER_SAMPLE (4u)
+#define FLAC__MAX_BITS_PER_SAMPLE (32u)
+#define FLAC__REFERENCE_CODEC_MAX_BITS_PER_SAMPLE (24u)
+#define FLAC__MAX_SAMPLE_RATE (655350u)
+#define FLAC__MAX_LPC_ORDER (32u)
+#define FLAC__SUBSET_MAX_LPC_ORDER_48000HZ (12u)
+#define FLAC__MIN_QLP_COEFF_PRECISION (5u)
+#define FLAC__MAX_QLP_COEFF_PRECISION (15u)
+#define FLAC__MAX_FIXED_ORDER (4u)
+#define FLAC__MAX_RICE_PARTITION_ORDER (15u)
+#define FLAC__SUBSET_MAX_RICE_PARTITION_ORDER (8u)
+#define FLAC__STREAM_SYNC_LENGTH (4u)
+
+/* include/FLAC/format.h:158-181, defined in format.c:56-67 */
+extern const char *FLAC__VERSION_STRING;          /* "1.2.1" */
+extern const char *FLAC__VENDOR_STRING;           /* "reference libFLAC 1.2.1 20070917": written into every VORBIS_COMMENT block */
+extern const FLAC__byte FLAC__STREAM_SYNC_STRING[4]; /* "fLaC" */
+extern const unsigned FLAC__STREAM_SYNC;          /* 0x664C6143 */
+extern const unsigned FLAC__STREAM_SYNC_LEN;      /* 32 bits */
 
 /* values and order of include/FLAC/stream_encoder.h:240-278 */
 typedef enum {
@@ -71,8 +105,15 @@ typedef enum { FLAC__STREAM_ENCODER_WRITE_STATUS_OK = 0, FLAC__STREAM_ENCODER_WR
 typedef enum { FLAC__STREAM_ENCODER_SEEK_STATUS_OK, FLAC__STREAM_ENCODER_SEEK_STATUS_ERROR, FLAC__STREAM_ENCODER_SEEK_STATUS_UNSUPPORTED } FLAC__StreamEncoderSeekStatus;
 typedef enum { FLAC__STREAM_ENCODER_TELL_STATUS_OK, FLAC__STREAM_ENCODER_TELL_STATUS_ERROR, FLAC__STREAM_ENCODER_TELL_STATUS_UNSUPPORTED } FLAC__StreamEncoderTellStatus;
 
+/* include/FLAC/stream_encoder.h:347-365: only the Ogg inits take a read callback */
+typedef enum { FLAC__STREAM_ENCODER_READ_STATUS_CONTINUE, FLAC__STREAM_ENCODER_READ_STATUS_END_OF_STREAM, FLAC__STREAM_ENCODER_READ_STATUS_ABORT, FLAC__STREAM_ENCODER_READ_STATUS_UNSUPPORTED } FLAC__StreamEncoderReadStatus;
+
 extern const char * const FLAC__StreamEncoderStateString[];
 extern const char * const FLAC__StreamEncoderInitStatusString[];
+extern const char * const FLAC__StreamEncoderReadStatusString[];
+extern const char * const FLAC__StreamEncoderWriteStatusString[];
+extern const char * const FLAC__StreamEncoderSeekStatusString[];
+extern const char * const FLAC__StreamEncoderTellStatusString[];
 
 /* Metadata blocks: types, field names and field order of include/FLAC/format.h:488-850, so
  * that block objects built by client code (or by the reference's metadata_object helpers) can
@@ -83,6 +124,7 @@ typedef enum {
 	FLAC__METADATA_TYPE_PICTURE = 6, FLAC__METADATA_TYPE_UNDEFINED = 7
 } FLAC__MetadataType;
 extern const char * const FLAC__MetadataTypeString[];
+extern const unsigned FLAC__STREAM_METADATA_IS_LAST_LEN, FLAC__STREAM_METADATA_TYPE_LEN, FLAC__STREAM_METADATA_LENGTH_LEN; /* 1, 7, 24 bits */
 
 typedef struct {
 	unsigned min_blocksize, max_blocksize;
@@ -128,11 +170,20 @@ typedef struct {
 	FLAC__StreamMetadata_CueSheet_Track *tracks;
 } FLAC__StreamMetadata_CueSheet;
 
-typedef enum {
+typedef enum {   /* the ID3v2 APIC picture kinds, include/FLAC/format.h:729-752 */
 	FLAC__STREAM_METADATA_PICTURE_TYPE_OTHER = 0, FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON_STANDARD = 1,
 	FLAC__STREAM_METADATA_PICTURE_TYPE_FILE_ICON = 2, FLAC__STREAM_METADATA_PICTURE_TYPE_FRONT_COVER = 3,
-	FLAC__STREAM_METADATA_PICTURE_TYPE_BACK_COVER = 4, FLAC__STREAM_METADATA_PICTURE_TYPE_UNDEFINED = 21
-} FLAC__StreamMetadata_Picture_Type;   /* 5..20: the remaining ID3v2 APIC kinds, passed through as numbers */
+	FLAC__STREAM_METADATA_PICTURE_TYPE_BACK_COVER = 4, FLAC__STREAM_METADATA_PICTURE_TYPE_LEAFLET_PAGE = 5,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_MEDIA = 6, FLAC__STREAM_METADATA_PICTURE_TYPE_LEAD_ARTIST = 7,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_ARTIST = 8, FLAC__STREAM_METADATA_PICTURE_TYPE_CONDUCTOR = 9,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_BAND = 10, FLAC__STREAM_METADATA_PICTURE_TYPE_COMPOSER = 11,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_LYRICIST = 12, FLAC__STREAM_METADATA_PICTURE_TYPE_RECORDING_LOCATION = 13,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_DURING_RECORDING = 14, FLAC__STREAM_METADATA_PICTURE_TYPE_DURING_PERFORMANCE = 15,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_VIDEO_SCREEN_CAPTURE = 16, FLAC__STREAM_METADATA_PICTURE_TYPE_FISH = 17,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_ILLUSTRATION = 18, FLAC__STREAM_METADATA_PICTURE_TYPE_BAND_LOGOTYPE = 19,
+	FLAC__STREAM_METADATA_PICTURE_TYPE_PUBLISHER_LOGOTYPE = 20, FLAC__STREAM_METADATA_PICTURE_TYPE_UNDEFINED = 21
+} FLAC__StreamMetadata_Picture_Type;
+extern const char * const FLAC__StreamMetadata_Picture_TypeString[];   /* 21 names */
 typedef struct {
 	FLAC__StreamMetadata_Picture_Type type;
 	char *mime_type;            /* NUL-terminated printable ASCII */
@@ -160,6 +211,32 @@ typedef struct {
 	} data;
 } FLAC__StreamMetadata;
 
+/* Bit widths of the fields of the metadata blocks as they lie in a stream (include/FLAC/format.h:506-860,
+ * values in format.c:69-119) */
+extern const unsigned
+	FLAC__STREAM_METADATA_STREAMINFO_MIN_BLOCK_SIZE_LEN, FLAC__STREAM_METADATA_STREAMINFO_MAX_BLOCK_SIZE_LEN,   /* 16, 16 */
+	FLAC__STREAM_METADATA_STREAMINFO_MIN_FRAME_SIZE_LEN, FLAC__STREAM_METADATA_STREAMINFO_MAX_FRAME_SIZE_LEN,   /* 24, 24 */
+	FLAC__STREAM_METADATA_STREAMINFO_SAMPLE_RATE_LEN, FLAC__STREAM_METADATA_STREAMINFO_CHANNELS_LEN,            /* 20, 3 */
+	FLAC__STREAM_METADATA_STREAMINFO_BITS_PER_SAMPLE_LEN, FLAC__STREAM_METADATA_STREAMINFO_TOTAL_SAMPLES_LEN,   /* 5, 36 */
+	FLAC__STREAM_METADATA_STREAMINFO_MD5SUM_LEN,                                                                /* 128 */
+	FLAC__STREAM_METADATA_APPLICATION_ID_LEN,                                                                   /* 32 */
+	FLAC__STREAM_METADATA_SEEKPOINT_SAMPLE_NUMBER_LEN, FLAC__STREAM_METADATA_SEEKPOINT_STREAM_OFFSET_LEN,       /* 64, 64 */
+	FLAC__STREAM_METADATA_SEEKPOINT_FRAME_SAMPLES_LEN,                                                          /* 16 */
+	FLAC__STREAM_METADATA_VORBIS_COMMENT_ENTRY_LENGTH_LEN, FLAC__STREAM_METADATA_VORBIS_COMMENT_NUM_COMMENTS_LEN, /* 32, 32 */
+	FLAC__STREAM_METADATA_CUESHEET_INDEX_OFFSET_LEN, FLAC__STREAM_METADATA_CUESHEET_INDEX_NUMBER_LEN,           /* 64, 8 */
+	FLAC__STREAM_METADATA_CUESHEET_INDEX_RESERVED_LEN,                                                          /* 24 */
+	FLAC__STREAM_METADATA_CUESHEET_TRACK_OFFSET_LEN, FLAC__STREAM_METADATA_CUESHEET_TRACK_NUMBER_LEN,           /* 64, 8 */
+	FLAC__STREAM_METADATA_CUESHEET_TRACK_ISRC_LEN, FLAC__STREAM_METADATA_CUESHEET_TRACK_TYPE_LEN,               /* 96, 1 */
+	FLAC__STREAM_METADATA_CUESHEET_TRACK_PRE_EMPHASIS_LEN, FLAC__STREAM_METADATA_CUESHEET_TRACK_RESERVED_LEN,   /* 1, 110 */
+	FLAC__STREAM_METADATA_CUESHEET_TRACK_NUM_INDICES_LEN,                                                       /* 8 */
+	FLAC__STREAM_METADATA_CUESHEET_MEDIA_CATALOG_NUMBER_LEN, FLAC__STREAM_METADATA_CUESHEET_LEAD_IN_LEN,        /* 1024, 64 */
+	FLAC__STREAM_METADATA_CUESHEET_IS_CD_LEN, FLAC__STREAM_METADATA_CUESHEET_RESERVED_LEN,                      /* 1, 2071 */
+	FLAC__STREAM_METADATA_CUESHEET_NUM_TRACKS_LEN,                                                              /* 8 */
+	FLAC__STREAM_METADATA_PICTURE_TYPE_LEN, FLAC__STREAM_METADATA_PICTURE_MIME_TYPE_LENGTH_LEN,                 /* 32 each */
+	FLAC__STREAM_METADATA_PICTURE_DESCRIPTION_LENGTH_LEN, FLAC__STREAM_METADATA_PICTURE_WIDTH_LEN,
+	FLAC__STREAM_METADATA_PICTURE_HEIGHT_LEN, FLAC__STREAM_METADATA_PICTURE_DEPTH_LEN,
+	FLAC__STREAM_METADATA_PICTURE_COLORS_LEN, FLAC__STREAM_METADATA_PICTURE_DATA_LENGTH_LEN;
+
 /* format.c:248-314, :396-523: the legality checks init applies to client blocks, and the sort the
  * encoder applies to a seek table before it is written back at finish(). */
 FLAC__bool FLAC__format_seektable_is_legal(const FLAC__StreamMetadata_SeekTable *seek_table);
@@ -167,6 +244,18 @@ unsigned FLAC__format_seektable_sort(FLAC__StreamMetadata_SeekTable *seek_table)
 FLAC__bool FLAC__format_vorbiscomment_entry_is_legal(const FLAC__byte *entry, unsigned length);
 FLAC__bool FLAC__format_cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet *cue_sheet, FLAC__bool check_cd_da_subset, const char **violation);
 FLAC__bool FLAC__format_picture_is_legal(const FLAC__StreamMetadata_Picture *picture, const char **violation);
+/* format.c:363-394: the two halves of a tag on their own; length (unsigned)(-1) = value is NUL-terminated */
+FLAC__bool FLAC__format_vorbiscomment_entry_name_is_legal(const char *name);
+FLAC__bool FLAC__format_vorbiscomment_entry_value_is_legal(const FLAC__byte *value, unsigned length);
+/* format.c:213-245: range checks of the format and of its streamable subset */
+FLAC__bool FLAC__format_sample_rate_is_valid(unsigned sample_rate);
+FLAC__bool FLAC__format_sample_rate_is_subset(unsigned sample_rate);
+FLAC__bool FLAC__format_blocksize_is_subset(unsigned blocksize, unsigned sample_rate);
+/* format.c:528-561 (private/format.h in the reference, exported by its library): the finest partition order a
+ * block of `blocksize` samples allows, and allows under a predictor of `predictor_order` */
+unsigned FLAC__format_get_max_rice_partition_order(unsigned blocksize, unsigned predictor_order);
+unsigned FLAC__format_get_max_rice_partition_order_from_blocksize(unsigned blocksize);
+unsigned FLAC__format_get_max_rice_partition_order_from_blocksize_limited_max_and_predictor_order(unsigned limit, unsigned blocksize, unsigned predictor_order);
 
 typedef struct FLAC__StreamEncoder FLAC__StreamEncoder;
 
@@ -208,6 +297,9 @@ FLAC__bool FLAC__stream_encoder_disable_constant_subframes(FLAC__StreamEncoder *
 FLAC__bool FLAC__stream_encoder_disable_fixed_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_disable_verbatim_subframes(FLAC__StreamEncoder *encoder, FLAC__bool value);
 FLAC__bool FLAC__stream_encoder_set_do_md5(FLAC__StreamEncoder *encoder, FLAC__bool value);
+FLAC__bool FLAC__stream_encoder_get_do_md5(const FLAC__StreamEncoder *encoder);   /* :1845-1851 */
+/* :1378-1393 without libogg: false, nothing stored */
+FLAC__bool FLAC__stream_encoder_set_ogg_serial_number(FLAC__StreamEncoder *encoder, long serial_number);
 
 FLAC__StreamEncoderState FLAC__stream_encoder_get_state(const FLAC__StreamEncoder *encoder);
 const char *FLAC__stream_encoder_get_resolved_state_string(const FLAC__StreamEncoder *encoder);
@@ -232,6 +324,14 @@ FLAC__uint64 FLAC__stream_encoder_get_total_samples_estimate(const FLAC__StreamE
 FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_stream(FLAC__StreamEncoder *encoder, FLAC__StreamEncoderWriteCallback write_callback, FLAC__StreamEncoderSeekCallback seek_callback, FLAC__StreamEncoderTellCallback tell_callback, FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data);
 FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_FILE(FLAC__StreamEncoder *encoder, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
 FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_file(FLAC__StreamEncoder *encoder, const char *filename, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+
+/* The Ogg inits of a library without Ogg transport (stream_encoder.c:1156-1308 over :640-662): the entrance
+ * checks run (ALREADY_INITIALIZED; init_ogg_file creates / truncates the file and ENCODER_ERROR + state IO_ERROR
+ * if that fails; the FILE is kept and closed by finish() / delete()), then ..._UNSUPPORTED_CONTAINER. */
+typedef FLAC__StreamEncoderReadStatus (*FLAC__StreamEncoderReadCallback)(const FLAC__StreamEncoder *encoder, FLAC__byte buffer[], size_t *bytes, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_stream(FLAC__StreamEncoder *encoder, FLAC__StreamEncoderReadCallback read_callback, FLAC__StreamEncoderWriteCallback write_callback, FLAC__StreamEncoderSeekCallback seek_callback, FLAC__StreamEncoderTellCallback tell_callback, FLAC__StreamEncoderMetadataCallback metadata_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_FILE(FLAC__StreamEncoder *encoder, FILE *file, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
+FLAC__StreamEncoderInitStatus FLAC__stream_encoder_init_ogg_file(FLAC__StreamEncoder *encoder, const char *filename, FLAC__StreamEncoderProgressCallback progress_callback, void *client_data);
 
 FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *encoder, const FLAC__int32 * const buffer[], unsigned samples);
 FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *encoder, const FLAC__int32 buffer[], unsigned samples);
@@ -309,6 +409,11 @@ typedef enum {
 extern const char * const FLAC__StreamDecoderStateString[];
 extern const char * const FLAC__StreamDecoderInitStatusString[];
 extern const char * const FLAC__StreamDecoderErrorStatusString[];
+extern const char * const FLAC__StreamDecoderReadStatusString[];
+extern const char * const FLAC__StreamDecoderSeekStatusString[];
+extern const char * const FLAC__StreamDecoderTellStatusString[];
+extern const char * const FLAC__StreamDecoderLengthStatusString[];
+extern const char * const FLAC__StreamDecoderWriteStatusString[];
 
 /* include/FLAC/format.h:376-443 */
 typedef enum {
@@ -329,11 +434,16 @@ typedef struct {
 	FLAC__uint8 crc;
 } FLAC__FrameHeader;
 typedef struct { FLAC__uint16 crc; } FLAC__FrameFooter;
+extern const char * const FLAC__FrameNumberTypeString[];
+/* the frame header's sync code and field widths (include/FLAC/format.h:445-470, format.c:121-132) */
+extern const unsigned FLAC__FRAME_HEADER_SYNC;   /* 0x3ffe */
+extern const unsigned
+	FLAC__FRAME_HEADER_SYNC_LEN, FLAC__FRAME_HEADER_RESERVED_LEN, FLAC__FRAME_HEADER_BLOCKING_STRATEGY_LEN,      /* 14, 1, 1 */
+	FLAC__FRAME_HEADER_BLOCK_SIZE_LEN, FLAC__FRAME_HEADER_SAMPLE_RATE_LEN, FLAC__FRAME_HEADER_CHANNEL_ASSIGNMENT_LEN, /* 4, 4, 4 */
+	FLAC__FRAME_HEADER_BITS_PER_SAMPLE_LEN, FLAC__FRAME_HEADER_ZERO_PAD_LEN, FLAC__FRAME_HEADER_CRC_LEN,         /* 3, 1, 8 */
+	FLAC__FRAME_FOOTER_CRC_LEN;                                                                                  /* 16 */
 
 /* include/FLAC/format.h:190-352: what the decoder tells the client about every subframe of a frame */
-#define FLAC__MAX_CHANNELS 8u
-#define FLAC__MAX_FIXED_ORDER 4u
-#define FLAC__MAX_LPC_ORDER 32u
 typedef enum { FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE = 0, FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 = 1 } FLAC__EntropyCodingMethodType;
 typedef struct {
 	unsigned *parameters;       /* the Rice parameter of each partition (the escape code for an escaped one) */
@@ -376,15 +486,26 @@ typedef struct {
 	} data;
 	unsigned wasted_bits;
 } FLAC__Subframe;
+/* subframe and residual field widths, type byte patterns, escape parameters (include/FLAC/format.h:190-370, format.c:134-158) */
+extern const unsigned
+	FLAC__ENTROPY_CODING_METHOD_TYPE_LEN, FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_ORDER_LEN,                /* 2, 4 */
+	FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_PARAMETER_LEN, FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2_PARAMETER_LEN, /* 4, 5 */
+	FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_RAW_LEN,                                                        /* 5 */
+	FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_ESCAPE_PARAMETER, FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2_ESCAPE_PARAMETER, /* 15, 31 */
+	FLAC__SUBFRAME_LPC_QLP_COEFF_PRECISION_LEN, FLAC__SUBFRAME_LPC_QLP_SHIFT_LEN,                               /* 4, 5 */
+	FLAC__SUBFRAME_ZERO_PAD_LEN, FLAC__SUBFRAME_TYPE_LEN, FLAC__SUBFRAME_WASTED_BITS_FLAG_LEN,                  /* 1, 6, 1 */
+	FLAC__SUBFRAME_TYPE_CONSTANT_BYTE_ALIGNED_MASK, FLAC__SUBFRAME_TYPE_VERBATIM_BYTE_ALIGNED_MASK,             /* 0x00, 0x02 */
+	FLAC__SUBFRAME_TYPE_FIXED_BYTE_ALIGNED_MASK, FLAC__SUBFRAME_TYPE_LPC_BYTE_ALIGNED_MASK;                     /* 0x10, 0x40 */
 extern const char * const FLAC__SubframeTypeString[];
 extern const char * const FLAC__EntropyCodingMethodTypeString[];
 extern const char * const FLAC__ChannelAssignmentString[];
 
-/* include/FLAC/format.h:472-476.  The decoder's write callback receives the frame as the reference's does, with two
- * differences, both about samples this decoder never holds on the host: `residual` of FIXED / LPC subframes is NULL
- * (the residual exists only on the device), and `data` of a VERBATIM subframe points at the channel's output samples
- * (equal to the coded ones unless the subframe has wasted bits).  Of a partitioned-Rice residual with a partition
- * order above 8 (outside the streamable subset) the first 256 parameters are filled in, the rest read 0. */
+/* include/FLAC/format.h:472-476.  The decoder's write callback receives the frame as the reference's does: `residual`
+ * of FIXED / LPC subframes and `data` of VERBATIM subframes hold what the stream carried (a second, sample-parallel
+ * pass on the device forms them again from the restored signal and they come back with the samples; a client that
+ * never reads them can switch the pass off with flacamd_stream_decoder_set_residuals(decoder, 0), after which
+ * `residual` is NULL and `data` points at the channel's output samples).  Of a partitioned-Rice residual with a
+ * partition order above 8 (outside the streamable subset) the first 256 parameters are filled in, the rest read 0. */
 typedef struct {
 	FLAC__FrameHeader header;
 	FLAC__Subframe subframes[FLAC__MAX_CHANNELS];
@@ -430,6 +551,14 @@ FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_stream(FLAC__StreamDecod
 FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_FILE(FLAC__StreamDecoder *decoder, FILE *file, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
 FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_file(FLAC__StreamDecoder *decoder, const char *filename, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
 
+/* The Ogg inits of a library without Ogg transport (stream_decoder.c:517-700 over :394-399): after the
+ * entrance checks (ALREADY_INITIALIZED, INVALID_CALLBACKS, ERROR_OPENING_FILE; an opened file is kept and
+ * closed by finish()) they return ..._UNSUPPORTED_CONTAINER; set_ogg_serial_number (:736-751) is false. */
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_stream(FLAC__StreamDecoder *decoder, FLAC__StreamDecoderReadCallback read_callback, FLAC__StreamDecoderSeekCallback seek_callback, FLAC__StreamDecoderTellCallback tell_callback, FLAC__StreamDecoderLengthCallback length_callback, FLAC__StreamDecoderEofCallback eof_callback, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_FILE(FLAC__StreamDecoder *decoder, FILE *file, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__StreamDecoderInitStatus FLAC__stream_decoder_init_ogg_file(FLAC__StreamDecoder *decoder, const char *filename, FLAC__StreamDecoderWriteCallback write_callback, FLAC__StreamDecoderMetadataCallback metadata_callback, FLAC__StreamDecoderErrorCallback error_callback, void *client_data);
+FLAC__bool FLAC__stream_decoder_set_ogg_serial_number(FLAC__StreamDecoder *decoder, long serial_number);
+
 FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *decoder);
 FLAC__bool FLAC__stream_decoder_flush(FLAC__StreamDecoder *decoder);
 FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *decoder);
@@ -442,6 +571,10 @@ FLAC__bool FLAC__stream_decoder_seek_absolute(FLAC__StreamDecoder *decoder, FLAC
 /* additions of this implementation: HIP device (default 0), frames per device batch (default 2048) */
 FLAC__bool flacamd_stream_decoder_set_device(FLAC__StreamDecoder *decoder, int device);
 FLAC__bool flacamd_stream_decoder_set_batch_frames(FLAC__StreamDecoder *decoder, unsigned frames);
+/* Whether FLAC__Frame carries the subframes' residuals (default on, as in the reference; the environment variable
+ * FLACAMD_DECODER_RESIDUALS=0 makes off the default for clients that cannot call this).  Off saves the residual pass
+ * and half of a batch's download. */
+FLAC__bool flacamd_stream_decoder_set_residuals(FLAC__StreamDecoder *decoder, FLAC__bool value);
 
 /* ---- encoder verify mode (declared here because they use the decoder's state type) ----
  * stream_encoder.c:1788-1827.  The verify decoder is the device decoder, run on every batch before

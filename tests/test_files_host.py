@@ -57,6 +57,12 @@ DS64 = struct.pack("<QQQI", 100, 8, 2, 0)
     (_w64([(b"fmt ", FMT16, None), (b"data", b"", None)]), "size of 0"),
     (b"fLaC" + b"\x84\0\0\x04abcd", "first metadata block is not STREAMINFO"),
     (b"fLaC" + b"\x80\0\0\x22" + b"\x10\0\x10\0" + b"\0" * 6 + b"\x0a\xc4\x42\xf0\0\0\0\0" + b"\0" * 16, "unknown total samples"),
+    (b"fLaC" + b"\x80\0\0\x22" + b"\x10\0\x10\0" + b"\0" * 6 + b"\x00\x00\x02\xf0\0\0\0\x64" + b"\0" * 16, "unsupported sample rate 0"),
+    # a chunk length near 2^64 must not wrap the position back into (or before) the file
+    (_w64([(b"fmt ", FMT16, None), (b"junk", b"", 0xFFFFFFFFFFFFFFD0), (b"data", b"\0" * 64, None)]), "didn't find data chunk"),
+    (_w64([(b"junk", b"", 0xFFFFFFFFFFFFFFF8), (b"fmt ", FMT16, None), (b"data", b"\0" * 64, None)]), "didn't find fmt chunk"),
+    (_w64([(b"fmt ", FMT16, None), (b"junk", b"", 1 << 63)]), "didn't find data chunk"),
+    (_riff([(b"fmt ", FMT16), (b"LIST", b"abcd")])[:-2] , "didn't find data chunk"),
     (b"FORM" + struct.pack(">I", 4) + b"AIFF", "didn't find COMM"),
     (b"FORM" + struct.pack(">I", 30) + b"AIFF" + b"COMM" + struct.pack(">IHIH", 18, 4, 10, 16) + b"\x40\x0e\xac\x44" + b"\0" * 6, "unsupported number of channels 4"),
 ])
