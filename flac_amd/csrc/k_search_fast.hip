@@ -74,10 +74,14 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 // PK = 3, 4: one channel, 16-bit and 32-bit samples.
 // LIGHT = 1: no candidate of the stream can need the 64-bit prediction sum or more than 24-bit
 // samples (decided on the host), so those paths and their registers are compiled out.
-template<typename SUM, int PK, int LIGHT>
-__device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCfg &c, const FaWork &w, uint32_t cg)
+// CGT != 0: the candidate group size is that constant (every LDS offset an immediate) and the development switches of
+// FaCfg::debug are compiled out; CGT == 0: both are run-time values.
+template<typename SUM, int PK, int LIGHT, int CGT>
+__device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCfg &c, const FaWork &w, uint32_t cg_arg)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const uint32_t cg = CGT ? (uint32_t)CGT : cg_arg;
+	const uint32_t dbg = CGT ? 0u : c.debug;
 
 	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig), f = g / c.nsig, s = g - f * c.nsig;   // the signals of a frame share an XCD
 	const uint32_t n = c.N;
@@ -112,12 +116,12 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 	// samples and coefficients fit 16 bits: two taps per instruction.  The side channel of a 16-bit
 	// stream has 17 bits nominally; the preparation stage notes when its samples fit 16 bits anyway
 	// (left and right within 32767 of each other, the usual case)
-	const bool use_dot2 = (bps <= 16u || ((sigflags & 2u) && c.bps <= 16u && !(c.debug & 0x20000u))) && !(c.debug & 0x8000u);
-	const bool sad_on = sizeof(SUM) == 4 && !(c.debug & 0x4000u);
+	const bool use_dot2 = (bps <= 16u || ((sigflags & 2u) && c.bps <= 16u && !(dbg & 0x20000u))) && !(dbg & 0x8000u);
+	const bool sad_on = sizeof(SUM) == 4 && !(dbg & 0x4000u);
 
 	const uint32_t qrows = c.max_lpc_order ? c.max_lpc_order : 1u;
 	const uint32_t part = i0 / dps0;
-	const bool stamp = (c.debug & 0x1000u) && tid == 0 && g < FA_DBG_WORDS / 8u;
+	const bool stamp = (dbg & 0x1000u) && tid == 0 && g < FA_DBG_WORDS / 8u;
 #define SF_STAMP(i) do { if(stamp) w.dbg[(size_t)g * 8u + (i)] = (unsigned long long)clock64(); } while(0)
 	SF_STAMP(0);
 
@@ -195,23 +199,27 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				raw[4*j] = v.x; raw[4*j+1] = v.y; raw[4*j+2] = v.z; raw[4*j+3] = v.w;
 			}
 			// L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), less the wasted bits.  Which one is the same for the whole
-			// workgroup: one branch around the loop instead of arithmetic that covers all four per sample
-			if(s == 0u) {
+			// workgroup: one branch around the loop instead of arithmetic that covers all four per sample; and a signal
+			// without wasted bits (nearly every one) takes the copy of the code in which the shift count is the literal 0
+			auto form = [&](const uint32_t wz) {
+				if(s == 0u) {
 #pragma unroll
-				for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> wasted;
-			}
-			else if(s == 1u) {
+					for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)(int16_t)(raw[j] & 0xffffu) >> wz;
+				}
+				else if(s == 1u) {
 #pragma unroll
-				for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)raw[j] >> (16u + wasted);
-			}
-			else if(s == 2u) {
+					for(int j = 0; j < SF_W; j++) xw[j] = (int32_t)raw[j] >> (16u + wz);
+				}
+				else if(s == 2u) {
 #pragma unroll
-				for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + wasted);
-			}
-			else {
+					for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + wz);
+				}
+				else {
 #pragma unroll
-				for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> wasted;
-			}
+					for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> wz;
+				}
+			};
+			if(wasted == 0u) form(0u); else form(wasted);
 		}
 		else {
 			// 32-bit stereo: two wide samples per 16-byte load
@@ -241,10 +249,6 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			}
 		}
 
-		// samples biased into unsigned order for the |a - b| instruction
-		uint32_t xb[SF_CH];
-#pragma unroll
-		for(int j = 0; j < SF_CH; j++) xb[j] = (uint32_t)xw[HIST + j] ^ 0x80000000u;
 		__syncthreads();
 		SF_STAMP(1);
 		if(tid < gn) {
@@ -270,7 +274,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		// ---- |residual| sums per finest partition.  Samples before `order` carry no residual: each
 		// sample of the chunk goes (statically) to one of three accumulators, of which thread 0 keeps
 		// only the tail, thread 1 the tail and the head, every other thread all three.
-		if(active && !(c.debug & 1u)) {
+		if(active && !(dbg & 1u)) {
 			SUM accT, accH, accM;
 			auto by_residual = [&](int sidx, int32_t rv, int P) {
 				const uint32_t m = abs_u32(rv);
@@ -279,9 +283,9 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			auto by_abs = [&](int sidx, int32_t x, int32_t pred, int P) { by_residual(sidx, (int32_t)((uint32_t)x - (uint32_t)pred), P); };
 			// |x - pred| + acc in one instruction on operands biased into unsigned order; equals the
 			// reference's abs(x - pred) whenever x - pred does not wrap, which |pred| <= 2^30 (shift >= 1) ensures
-			auto by_sad = [&](int sidx, int32_t, int32_t pred, int P) {
-				const uint32_t pb = (uint32_t)pred ^ 0x80000000u;
-				if(sidx + SF_CH < P) accM = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accH); else accT = (SUM)sad_u32(xb[sidx], pb, (uint32_t)accT);
+			auto by_sad = [&](int sidx, int32_t x, int32_t pred, int P) {
+				const uint32_t xb = (uint32_t)x ^ 0x80000000u, pb = (uint32_t)pred ^ 0x80000000u;
+				if(sidx + SF_CH < P) accM = (SUM)sad_u32(xb, pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xb, pb, (uint32_t)accH); else accT = (SUM)sad_u32(xb, pb, (uint32_t)accT);
 			};
 			auto deposit = [&](uint32_t ci) {
 				const SUM v = accT + (tid >= 1u ? accH : (SUM)0) + (tid >= 2u ? accM : (SUM)0);
@@ -341,35 +345,47 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 #pragma unroll
 				for(int j = 1; j < SF_W; j++) xp[j] = pack_lo16(xw[j], xw[j - 1]);
 				// |x - pred| with both sides moved into unsigned order by 2^(31 - shift): the sums start from 2^31, so that
-				// a logical shift yields pred + 2^(31 - shift) directly, and the samples carry the same offset, which is
-				// redone only when the shift differs from the previous candidate's (|x| < 2^15 and shift <= 15 keep x + offset positive)
-				uint32_t xs[SF_CH], xs_shift = 0xffffffffu;
-				for(uint32_t ci = nfixed; ci < gn; ci++) {
-					const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)chdr[ci]);
-					const uint32_t order = FA_CAND_ORDER(hdr), shift = FA_CAND_SHIFT(hdr);
-					accT = 0; accH = 0; accM = 0;
-					if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
-					else {
-						uint32_t qp[HIST / 2];
-						const uint2 *q2 = (const uint2*)(cqp + ci * (HIST / 2));
-						const uint2 pa = q2[0], pb = q2[1], pc = q2[2];
-						qp[0] = pa.x; qp[1] = pa.y; qp[2] = pb.x; qp[3] = pb.y; qp[4] = pc.x; qp[5] = pc.y;
-						if(sad_on && shift >= 1u) {
-							if(shift != xs_shift) {
-								const uint32_t off = 1u << (31u - shift);
+				// a logical shift yields pred + 2^(31 - shift) directly, and the samples carry the same offset (|x| < 2^15 and
+				// shift <= 15 keep x + offset positive).  The offset samples cost an instruction each per shift value, so the
+				// candidates are taken shift by shift, not in index order (their place in the arg-min is their index either
+				// way): each lane below gn holds the header of candidate `lane`, a ballot collects the candidates that share
+				// the shift of the first one not yet done.  A signal's twelve orders have two or three shift values between them.
+				uint32_t xs[SF_CH];
+				const uint32_t lane_hdr = (lane < gn) ? chdr[lane] : 0u;
+				unsigned long long todo = __ballot(lane >= nfixed && lane < gn);
+				while(todo) {
+					const uint32_t first = (uint32_t)__builtin_ctzll(todo);
+					const uint32_t shift = FA_CAND_SHIFT((uint32_t)__builtin_amdgcn_readlane((int)lane_hdr, (int)first));
+					unsigned long long grp = __ballot(FA_CAND_SHIFT(lane_hdr) == shift) & todo;
+					todo &= ~grp;
+					if(sad_on && shift >= 1u) {
+						const uint32_t off = 1u << (31u - shift);
 #pragma unroll
-								for(int j = 0; j < SF_CH; j++) xs[j] = (xb[j] ^ 0x80000000u) + off;
-								xs_shift = shift;
-							}
-							auto by_sum = [&](int sidx, int32_t sum, int P) {
-								const uint32_t pb = (uint32_t)sum >> shift;
-								if(sidx + SF_CH < P) accM = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accH); else accT = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accT);
-							};
-							lpc_sum_each_dot2_dispatch(order, xp, qp, (int32_t)0x80000000u, by_sum);
-						}
-						else lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_abs);
+						for(int j = 0; j < SF_CH; j++) xs[j] = (uint32_t)xw[HIST + j] + off;
 					}
-					deposit(ci);
+					while(grp) {
+						const uint32_t ci = (uint32_t)__builtin_ctzll(grp);
+						grp &= grp - 1ull;
+						const uint32_t hdr = (uint32_t)__builtin_amdgcn_readlane((int)lane_hdr, (int)ci);
+						const uint32_t order = FA_CAND_ORDER(hdr);
+						accT = 0; accH = 0; accM = 0;
+						if(!LIGHT && FA_CAND_WIDE(hdr)) { int32_t q[HIST]; SF_LOAD_Q(ci, q); lpc_pred_each_dispatch<MAC_WIDE>(order, xw, q, shift, by_abs); }
+						else {
+							uint32_t qp[HIST / 2];
+							const uint2 *q2 = (const uint2*)(cqp + ci * (HIST / 2));
+							const uint2 pa = q2[0], pb = q2[1], pc = q2[2];
+							qp[0] = pa.x; qp[1] = pa.y; qp[2] = pb.x; qp[3] = pb.y; qp[4] = pc.x; qp[5] = pc.y;
+							if(sad_on && shift >= 1u) {
+								auto by_sum = [&](int sidx, int32_t sum, int P) {
+									const uint32_t pb = (uint32_t)sum >> shift;
+									if(sidx + SF_CH < P) accM = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accM); else if(sidx < P) accH = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accH); else accT = (SUM)sad_u32(xs[sidx], pb, (uint32_t)accT);
+								};
+								lpc_sum_each_dot2_dispatch(order, xp, qp, (int32_t)0x80000000u, by_sum);
+							}
+							else lpc_pred_each_dot2_dispatch(order, xw, xp, qp, shift, by_abs);
+						}
+						deposit(ci);
+					}
 				}
 			}
 			else {
@@ -404,7 +420,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		// order walk lane 0 through the totals of level 6, 6 + 5, 6 + 5 + 4.  Lane 0 of the group then picks the
 		// best order (searched max -> min, strict '<') and leaves estimate and order; the Rice parameters are
 		// not kept: the first wave works them out again for the one candidate that wins.
-		if(!(c.debug & 2u)) {
+		if(!(dbg & 2u)) {
 			const uint32_t j = tid & 7u;
 			const uint32_t lvU = (0x64544540u >> (4u * j)) & 15u;                 // level of this lane's outer partition (lane 0: none)
 			const bool firstU = j == 1u || j == 2u || j == 7u;                     // ... and whether it is the first partition of that level
@@ -497,7 +513,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		SF_STAMP(5);
 
 		// ---- first wave: ordered arg-min over the group (estimate, then candidate index)
-		if(tid < 64u && !(c.debug & 2u)) {
+		if(tid < 64u && !(dbg & 2u)) {
 			unsigned long long bk = (lane < gn) ? ckey[lane] : ~0ull;
 #pragma unroll
 			for(int o = 32; o > 0; o >>= 1) { const unsigned long long t = (unsigned long long)__shfl_xor((long long)bk, o, 64); bk = t < bk ? t : bk; }
@@ -564,10 +580,10 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 // headline workload: 512 x 8 samples at 2 / 3 workgroups per CU 4.9 / 4.3 ms per hour of audio, this shape
 // 3.8 ms; tighter caps (5 or 6 workgroups) gain 2 % and spill 80-100 bytes per lane; evaluating three
 // candidates side by side in a wave spills and gains nothing.  Other sample layouts take the general kernel.
-template<typename SUM, int PK, int LIGHT>
+template<typename SUM, int PK, int LIGHT, int CGT>
 __global__ void __launch_bounds__(SF_THREADS, (PK == 2 || sizeof(SUM) == 8 || (PK == 4 && !LIGHT)) ? 3 : 4) fa_search_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg)
 {
-	sf_body<SUM, PK, LIGHT>(pcm, c, w, cg);
+	sf_body<SUM, PK, LIGHT, CGT>(pcm, c, w, cg);
 }
 extern "C" size_t fa_search_fast_lds_bytes(const FaCfg *c, uint32_t cg, int sum64)
 {
@@ -607,14 +623,19 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 	const uint32_t max_prec = c->prec_search ? FA_MAX_QLP_PRECISION : c->qlp_precision;
 	const uint32_t max_bps = c->bps + (c->midside ? 1u : 0u);
 	const bool light = !sum64 && max_bps <= 24u && max_bps + max_prec + lg <= 32u;
-#define SF_LAUNCH(SUMT, PKV, LV) do { \
-		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV, LV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
+#define SF_LAUNCH_CG(SUMT, PKV, LV, CGV) do { \
+		(void)hipFuncSetAttribute((const void*)fa_search_fast_kernel<SUMT, PKV, LV, CGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+		hipLaunchKernelGGL((fa_search_fast_kernel<SUMT, PKV, LV, CGV>), grid, block, lds, st, pcm, *c, *w, cg); } while(0)
+#define SF_LAUNCH(SUMT, PKV, LV) SF_LAUNCH_CG(SUMT, PKV, LV, 0)
 #define SF_LAUNCH_PK(SUMT, LV) do { if(pk == 1) SF_LAUNCH(SUMT, 1, LV); else if(pk == 2) SF_LAUNCH(SUMT, 2, LV); else if(pk == 3) SF_LAUNCH(SUMT, 3, LV); else SF_LAUNCH(SUMT, 4, LV); } while(0)
-	if(sum64) SF_LAUNCH_PK(unsigned long long, 0);
+	// 16-bit stereo at the exhaustive presets (five fixed + twelve linear predictors per signal): the variant with the
+	// group size and the production switches as constants
+	if(!sum64 && light && pk == 1 && cg == 17u && c->debug == 0u) SF_LAUNCH_CG(uint32_t, 1, 1, 17);
+	else if(sum64) SF_LAUNCH_PK(unsigned long long, 0);
 	else if(light) SF_LAUNCH_PK(uint32_t, 1);
 	else SF_LAUNCH_PK(uint32_t, 0);
 #undef SF_LAUNCH_PK
 #undef SF_LAUNCH
+#undef SF_LAUNCH_CG
 
 }
