@@ -552,9 +552,17 @@ __global__ void __launch_bounds__(64) fa_assign_kernel(FaCfg c, FaWork w)
 // before the second is looked at, it needs 79 registers: six workgroups per CU, nothing spilled.  Per hour of audio:
 // 0.90 ms at four workgroups per CU, 0.80 at five, 0.75 at six, 0.73 at seven (five registers in scratch memory, which
 // is 0.2 GB of traffic), 1.00 at eight.
-template<int NSUB, bool PACKED16, bool NARROW>
-__global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t bitbuf_words)
+// CD8: the stream is 16-bit / 44.1 kHz stereo in blocks of 4096 with mid/side and partition orders up to 6, one stream per
+// batch, frames written in place (`flac -8`, -5 ... on CD audio; the launcher checks every field): those parameters are
+// constants of this variant instead of values that occupy scalar registers across the whole kernel.
+template<int NSUB, bool PACKED16, bool NARROW, bool CD8>
+__global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) fa_pack_fast_kernel(const void *__restrict__ pcm, FaCfg c_arg, FaWork w, uint32_t bitbuf_words)
 {
+	FaCfg c = c_arg;
+	if(CD8) {
+		c.N = 4096u; c.channels = 2u; c.bps = 16u; c.rate = 44100u; c.nsig = 4u; c.midside = 1u; c.multi = 0u; c.max_po = 6u; c.debug = 0u;
+		c.pcm_format = FLACAMD_PCM_S16; c.direct_out = 1u;
+	}
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ PackFastShared sh;
 	uint32_t *bitbuf = (uint32_t*)lds_raw;
@@ -1055,9 +1063,11 @@ extern "C" void fa_launch_pack(const void *pcm, const FaCfg *c, const FaWork *w,
 #define PF_LAUNCH(...) do { \
 			(void)hipFuncSetAttribute((const void*)fa_pack_fast_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
 			hipLaunchKernelGGL((fa_pack_fast_kernel<__VA_ARGS__>), dim3(c->F), dim3(PF_THREADS), lds, st, pcm, *c, *w, words); } while(0)
-		if(c->channels == 2 && c->pcm_format == FLACAMD_PCM_S16) { if(narrow) PF_LAUNCH(2, true, true); else PF_LAUNCH(2, true, false); }
-		else if(c->channels == 2) PF_LAUNCH(2, false, false);
-		else PF_LAUNCH(1, false, false);
+		const bool cd8 = narrow && c->N == 4096u && c->channels == 2u && c->bps == 16u && c->rate == 44100u && c->nsig == 4u && c->midside == 1u && c->multi == 0u
+			&& c->max_po == 6u && c->debug == 0u && c->pcm_format == FLACAMD_PCM_S16 && c->direct_out == 1u;
+		if(c->channels == 2 && c->pcm_format == FLACAMD_PCM_S16) { if(cd8) PF_LAUNCH(2, true, true, true); else if(narrow) PF_LAUNCH(2, true, true, false); else PF_LAUNCH(2, true, false, false); }
+		else if(c->channels == 2) PF_LAUNCH(2, false, false, false);
+		else PF_LAUNCH(1, false, false, false);
 #undef PF_LAUNCH
 		return;
 	}

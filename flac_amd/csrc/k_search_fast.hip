@@ -77,11 +77,18 @@ __device__ __forceinline__ void sf_price(SUM sum, uint32_t nsamp, bool use_given
 // CGT != 0: the candidate group size is that constant (every LDS offset an immediate) and the development switches of
 // FaCfg::debug are compiled out; CGT == 0: both are run-time values.
 template<typename SUM, int PK, int LIGHT, int CGT>
-__device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCfg &c, const FaWork &w, uint32_t cg_arg)
+__device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCfg &c_in, const FaWork &w, uint32_t cg_arg)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const uint32_t cg = CGT ? (uint32_t)CGT : cg_arg;
-	const uint32_t dbg = CGT ? 0u : c.debug;
+	const uint32_t dbg = CGT ? 0u : c_in.debug;
+	// the stream parameters the kernel works from: run-time values, or (CGT == 17) those of `flac -8` on 16-bit stereo
+	// with blocks of 4096, which the launcher has checked field by field
+	struct View { uint32_t N, bps, disable_constant, disable_verbatim, fixed_psum, k_limit, max_cand, max_lpc_order, max_po, midside, min_po, multi, nsig, cand_stride; };
+	const View c = CGT == 17
+		? View{ 4096u, 16u, 0u, 0u, 1u, 15u, 17u, 12u, 6u, 1u, 0u, 0u, 4u, 16u }
+		: View{ c_in.N, c_in.bps, c_in.disable_constant, c_in.disable_verbatim, c_in.fixed_psum, c_in.k_limit, c_in.max_cand, c_in.max_lpc_order, c_in.max_po, c_in.midside, c_in.min_po, c_in.multi, c_in.nsig, c_in.cand_stride };
+	auto cand_idx = [&](uint32_t sig, uint32_t slot) -> size_t { return ((size_t)sig * c.max_cand + slot) * c.cand_stride; };
 
 	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig), f = g / c.nsig, s = g - f * c.nsig;   // the signals of a frame share an XCD
 	const uint32_t n = c.N;
@@ -136,14 +143,14 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		// candidate headers and coefficients of this group: one parallel fetch into LDS, for every
 		// slot of the group whether used or not, so that the loads do not wait for the candidate count
 		for(uint32_t t = tid; t < cg * (HIST / 2 + 1u); t += SF_THREADS) {
-			if(t < cg) chdr[t] = (cb + t < c.max_cand) ? w.cand_hdr[fa_cand_idx(c, g, (cb + t))] : 0u;
+			if(t < cg) chdr[t] = (cb + t < c.max_cand) ? w.cand_hdr[cand_idx(g, (cb + t))] : 0u;
 			else {
 				const uint32_t tt = t - cg, ci = tt / (HIST / 2), m = tt - ci * (HIST / 2);
 				const bool ok = cb + ci < c.max_cand;
 				// header and coefficient pair fetched side by side (a slot that does not exist reads the signal's first record
 				// instead, a row the coefficient table does not have reads row 0: no load hangs on a condition another load decides);
 				// rows at and above the candidate's order are not written by the model stage: taken as zero
-				const size_t rec = fa_cand_idx(c, g, ok ? cb + ci : 0u);
+				const size_t rec = cand_idx(g, ok ? cb + ci : 0u);
 				const uint32_t hdr_ci = w.cand_hdr[rec];
 				const int32_t l0 = w.cand_q[rec + (2u * m < qrows ? 2u * m : 0u)], l1 = w.cand_q[rec + (2u * m + 1u < qrows ? 2u * m + 1u : 0u)];
 				const uint32_t ord = ok ? FA_CAND_ORDER(hdr_ci) : 0u;
@@ -630,7 +637,10 @@ extern "C" void fa_launch_search_fast(const void *pcm, const FaCfg *c, const FaW
 #define SF_LAUNCH_PK(SUMT, LV) do { if(pk == 1) SF_LAUNCH(SUMT, 1, LV); else if(pk == 2) SF_LAUNCH(SUMT, 2, LV); else if(pk == 3) SF_LAUNCH(SUMT, 3, LV); else SF_LAUNCH(SUMT, 4, LV); } while(0)
 	// 16-bit stereo at the exhaustive presets (five fixed + twelve linear predictors per signal): the variant with the
 	// group size and the production switches as constants
-	if(!sum64 && light && pk == 1 && cg == 17u && c->debug == 0u) SF_LAUNCH_CG(uint32_t, 1, 1, 17);
+	const bool cd8 = !sum64 && light && pk == 1 && cg == 17u && c->debug == 0u && c->N == 4096u && c->bps == 16u && !c->disable_constant && !c->disable_verbatim
+		&& c->fixed_psum == 1u && c->k_limit == 15u && c->max_cand == 17u && c->max_lpc_order == 12u && c->max_po == 6u && c->midside == 1u && c->min_po == 0u && c->multi == 0u
+		&& c->nsig == 4u && c->cand_stride == 16u;
+	if(cd8) SF_LAUNCH_CG(uint32_t, 1, 1, 17);
 	else if(sum64) SF_LAUNCH_PK(unsigned long long, 0);
 	else if(light) SF_LAUNCH_PK(uint32_t, 1);
 	else SF_LAUNCH_PK(uint32_t, 0);
