@@ -29,23 +29,34 @@ QUEUE_DEPTH = 16   # FLACAMD_QUEUE_DEPTH: batches one encoder may have outstandi
 
 
 # kernel that runs each timed stage for this workload (16-bit stereo, blocksize 4096)
-KERNEL_OF_STAGE = {"autoc_beside_prep": "fa_autoc_ms16_kernel<13>", "prep_join_wait": "fa_prep_stereo16_lean_kernel", "model": "fa_model_kernel<12>",
-                   "search": "fa_search_fast_kernel<unsigned int, 1, 1>", "pack": "fa_pack_fast_kernel<2, true, true>", "gather": "fa_scan_kernel"}
+KERNEL_OF_STAGE = {"autoc_beside_prep": "fa_autoc_ms16_kernel<13, 1>", "prep_join_wait": "fa_prep_stereo16_lean_kernel", "model": "fa_model_kernel<12>",
+                   "search": "fa_search_fast_kernel<unsigned int, 1, 1, 17>", "pack": "fa_pack_fast_kernel<2, true, true, true>", "gather": "fa_scan_kernel"}
 
 
-def pmc_traffic(kernel, minutes):
+PMC_SUMMARY = "profiles/r3_pmc_summary.json"
+
+
+def pmc_traffic(kernel, minutes, stage_ms):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r2_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate
-    runs, FETCH_SIZE doubled as measured for gfx950), or None when no pass covers it."""
+    command (PMC_SUMMARY: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled
+    as measured for gfx950).  The counters cannot be collected inside a timed run, so the figure
+    is only reported while it still describes the kernel that ran: (None, why) when no pass covers
+    the kernel or when the profiled average duration differs from this run's stage time by more
+    than 10 % (the kernel has changed since the passes were made)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             summ = json.load(f)
         if summ.get("minutes") != minutes:
-            return None
+            return None, "the committed passes cover %s minutes per step, this run %s" % (summ.get("minutes"), minutes)
         k = summ["kernels"].get(kernel)
-        return None if k is None else int(k["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+        if k is None:
+            return None, "no committed pass covers this kernel"
+        avg = k.get("avg_ms")
+        if avg is None or stage_ms <= 0 or abs(avg - stage_ms) / stage_ms > 0.10:
+            return None, "stale: profiled average %s ms against %.4f ms in this run" % (avg, stage_ms)
+        return int(k["hbm_bytes_per_launch"]), "committed rocprofv3 PMC passes of this command (%s, kernel average %.4f ms there, %.4f ms here), not measured in this run" % (PMC_SUMMARY, avg, stage_ms)
+    except (OSError, ValueError, KeyError) as ex:
+        return None, "no usable summary: %s" % ex
 
 
 def build_workload(seconds_base=60, repeats=60):
@@ -114,7 +125,99 @@ def cpu_baseline(base_pcm, budget_s=12.0):
     return out
 
 
-def api_rates(base_pcm, minutes):
+def _wav_bytes(pcm16, rate):
+    import struct
+    data = np.ascontiguousarray(pcm16.astype("<i2")).tobytes()
+    ch = pcm16.shape[1]
+    return b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * ch * 2, ch * 2, 16) + b"data" + struct.pack("<I", len(data)) + data
+
+
+def _raw24(pcm32):
+    return np.ascontiguousarray(pcm32.astype("<i4")).reshape(-1, 1).view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+
+
+def cpu_tool_baselines(base_pcm, clips=24):
+    """The reference's own command line tool (oracle/_ref/flac, built from the reference's sources) on files in /dev/shm
+    (page cache), single stream, best wall time: `flac -s -f -8` on the 60 s programme of the headline workload, and a
+    bounded sample of each other configuration: `-8 -e -p` on 10 s of the 8-channel 24-bit/96 kHz programme, `flac -d` of
+    the -8 file, `-5` on the first `clips` clips of the clip workload's draw."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "flac")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/flac not built"}
+    from flac_amd import synth
+    tmp = tempfile.mkdtemp(prefix="flacamd_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+    def best(cmd, reps):
+        b = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("%s: %s" % (" ".join(cmd), r.stderr[-200:]))
+            b = min(b, dt)
+        return b
+
+    out = {}
+    try:
+        n = base_pcm.shape[0]
+        with open(os.path.join(tmp, "c2.wav"), "wb") as f:
+            f.write(_wav_bytes(base_pcm, RATE))
+        dt = best([exe, "-s", "-f", "-8", "-o", "c2.flac", "c2.wav"], 3)
+        out["c2_tool"] = {"value": round(n / dt / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "reference", "seconds": round(dt, 3),
+                          "sample": "flac -s -f -8 on the 60 s 16/44.1 stereo programme as a WAVE file in /dev/shm, best of 3 (MD5 on, file written)"}
+        dt = best([exe, "-s", "-f", "-d", "-o", "c4.wav", "c2.flac"], 3)
+        out["c4_decode"] = {"value": round(n / dt / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": "reference", "seconds": round(dt, 3),
+                            "sample": "flac -s -f -d of that file's -8 stream (MD5 checked, WAVE written to /dev/shm), best of 3"}
+        c3 = synth.multichannel_24(10.0, rate=96000, channels=8, seed=4321)
+        with open(os.path.join(tmp, "c3.raw"), "wb") as f:
+            f.write(_raw24(c3))
+        dt = best([exe, "-s", "-f", "-8", "-e", "-p", "--force-raw-format", "--endian=little", "--sign=signed", "--channels=8", "--bps=24", "--sample-rate=96000",
+                   "-o", "c3.flac", "c3.raw"], 1)
+        out["c3"] = {"value": round(len(c3) / dt / 1e6, 4), "unit": "MSamples/s (wide)", "channel_samples_per_s_M": round(8 * len(c3) / dt / 1e6, 3), "cores": 1, "kind": "reference",
+                     "seconds": round(dt, 3), "sample": "flac -8 -e -p on the 10 s 8-channel 24-bit/96 kHz programme (raw input in /dev/shm), one pass"}
+        # the clip workload's draw (same generator and seed as config_c5), its first clips
+        rng = np.random.default_rng(777)
+        nall = 10000
+        dur = rng.uniform(1.0, 30.0, nall)
+        bps = np.where(rng.random(nall) < 0.5, 16, 24)
+        rate = np.where(rng.random(nall) < 0.5, 44100, 48000)
+        ch = np.where(rng.random(nall) < 0.5, 1, 2)
+        progs = {}
+        wide = 0
+        cmds = []
+        for i in range(clips):
+            key = (int(ch[i]), int(bps[i]), int(rate[i]))
+            if key not in progs:
+                c, b, r = key
+                progs[key] = synth.music_like(30.0, rate=r, seed=5)[:, :c] if b == 16 else synth.multichannel_24(30.0, rate=r, channels=c, seed=9)
+            c, b, r = key
+            ln = int(dur[i] * r)
+            name = "clip%d.raw" % i
+            with open(os.path.join(tmp, name), "wb") as f:
+                f.write(np.ascontiguousarray(progs[key][:ln].astype("<i2")).tobytes() if b == 16 else _raw24(progs[key][:ln]))
+            cmds.append([exe, "-s", "-f", "-5", "--force-raw-format", "--endian=little", "--sign=signed", "--channels=%d" % c, "--bps=%d" % b, "--sample-rate=%d" % r,
+                         "-o", "clip%d.flac" % i, name])
+            wide += ln
+        t0 = time.perf_counter()
+        for cmd in cmds:
+            r_ = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+            if r_.returncode != 0:
+                raise RuntimeError("%s: %s" % (" ".join(cmd), r_.stderr[-200:]))
+        dt = time.perf_counter() - t0
+        out["c5_clips"] = {"value": round(wide / dt / 1e6, 3), "unit": "MSamples/s (wide)", "clips_per_s": round(clips / dt, 2), "cores": 1, "kind": "reference", "seconds": round(dt, 3),
+                           "sample": "flac -5, one process per clip, on the first %d clips of the workload's draw (raw files in /dev/shm), wall clock incl. process start" % clips}
+    except Exception as ex:   # what was measured stands
+        out["error"] = "%s: %s" % (type(ex).__name__, ex)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def api_rates(base_pcm, minutes, ndev=1):
     """Rates through the boundary a libFLAC client sees (tools/api_rate.cpp, a compiled C++ client of the
     C ABI run as a child process): PCM in pageable host memory as int32, frames to a C write callback.
     PCIe-inclusive, so never `value`."""
@@ -127,7 +230,7 @@ def api_rates(base_pcm, minutes):
         base_pcm.astype(np.int16).tofile(f)
         f.flush()
         try:
-            out = subprocess.run([exe, f.name, str(minutes), "8", "2048", "1"], capture_output=True, text=True, timeout=240)
+            out = subprocess.run([exe, f.name, str(minutes), "8", "2048", str(ndev)], capture_output=True, text=True, timeout=300)
         except subprocess.TimeoutExpired:
             return {"error": "api_rate timed out"}
     if out.returncode != 0:
@@ -276,56 +379,116 @@ def config_c5(dev, local, nclips=10000):
                          "frac": round((pcm_bytes + total_bytes) / dt / 1e9 / HBM_PEAK_GBS, 5), "note": "whole batch incl. per-clip MD5 on the device (one lane per clip) and stream assembly"}}
 
 
-def sharded_hour(enc, d_pcm, nsamples, nframes, rank, world, dev, dist, cpu_collectives):
-    """Strong scaling of the headline hour: rank r codes frames [r F/W, (r+1) F/W), the sizes and bytes are gathered to
-    rank 0 (RCCL; no collective on the data path itself) and laid end to end there.  The stitched stream must be the
-    same bytes for every W: rank 0 reports its length and CRC-32."""
+def sharded_stream(base, params, rank, world, local, dev, dist, host_group, rehearsal, hours=8):
+    """Strong scaling of ONE long stream: `hours` of the headline programme cut into `world` frame ranges, rank r codes
+    frames [r F/W, (r+1) F/W) (frames are independent given their samples and number: no collective on the data path), then
+    the frames are brought together on rank 0 and laid end to end, by both routes north_star names:
+      host  every rank downloads its frames to page-locked memory, the bytes go to rank 0 over the host (gloo) and are
+            concatenated there - what the in-process pipe does with its lanes;
+      rccl  sizes all-gathered and frame bytes gathered device to device over xGMI (RCCL), concatenated on rank 0's GPU.
+    Both must give the same bytes for every W (length and CRC-32 reported)."""
     import zlib
     import torch
     from flac_amd import engine, sharding
-    f0, f1 = sharding.frame_ranges(nframes, world, 1)[rank]
-    ns = min(f1 * FRAME, nsamples) - f0 * FRAME
-    cap = enc.max_output_bytes(max(f1 - f0, 1))
+    L = base.shape[0]
+    nS = hours * 3600 * RATE
+    F = (nS + FRAME - 1) // FRAME
+    f0, f1 = sharding.frame_ranges(F, world, 1)[rank]
+    s0, s1 = f0 * FRAME, min(f1 * FRAME, nS)
+    ns = s1 - s0
+    base_t = torch.from_numpy(np.ascontiguousarray(base.astype(np.int16))).to(dev)
+    d_pcm = torch.empty((ns, 2), dtype=torch.int16, device=dev)   # this rank's range of the tiled programme
+    at, src = 0, s0 % L
+    while at < ns:
+        k = min(L - src, ns - at)
+        d_pcm[at:at + k] = base_t[src:src + k]
+        at += k
+        src = 0
+    nf = f1 - f0
+    enc = engine.Encoder(params, max_frames=max(nf, 1), device=local)
+    cap = enc.max_output_bytes(max(nf, 1))
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_fb = torch.empty(max(f1 - f0, 1), dtype=torch.int32, device=dev)
-    cdev = "cpu" if cpu_collectives else dev
+    d_fb = torch.empty(max(nf, 1), dtype=torch.int32, device=dev)
+    h_out = torch.empty(cap, dtype=torch.uint8).pin_memory()
+    coll_dev = "cpu" if rehearsal else dev
 
-    def once():
-        total = enc.encode_device(d_pcm.data_ptr() + f0 * FRAME * 4, engine.PCM_S16, ns, d_out.data_ptr(), cap, d_fb.data_ptr(), final=(f1 == nframes), first_frame=f0) if f1 > f0 else 0
+    def encode():
+        return enc.encode_device(d_pcm.data_ptr(), engine.PCM_S16, ns, d_out.data_ptr(), cap, d_fb.data_ptr(), final=(f1 == F), first_frame=f0) if nf else 0
+
+    def counts_of(total, group, where):
+        if world == 1:
+            return [total]
+        mine = torch.tensor([total], dtype=torch.int64, device=where)
+        every = [torch.zeros(1, dtype=torch.int64, device=where) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        return [int(c[0]) for c in every]
+
+    def host_route():
+        total = encode()
+        h_out[:total].copy_(d_out[:total], non_blocking=True)
+        torch.cuda.synchronize()
+        counts = counts_of(total, host_group, "cpu")
+        if world == 1:
+            return h_out[:total], total
+        if rank == 0:
+            whole = torch.empty(sum(counts), dtype=torch.uint8)
+            whole[:counts[0]] = h_out[:counts[0]]
+            at, reqs = counts[0], []
+            for r in range(1, world):
+                reqs.append(dist.irecv(whole[at:at + counts[r]], src=r, group=host_group))
+                at += counts[r]
+            for q in reqs:
+                q.wait()
+            return whole, int(whole.numel())
+        dist.send(h_out[:total], dst=0, group=host_group)
+        return None, 0
+
+    def rccl_route():
+        total = encode()
+        counts = counts_of(total, None, coll_dev)
         if world == 1:
             return d_out[:total], total
-        mine = torch.tensor([f1 - f0, total], dtype=torch.int64, device=cdev)
-        counts = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(counts, mine)
-        counts = [(int(c[0]), int(c[1])) for c in counts]
-        max_b = max(c[1] for c in counts)
+        max_b = max(counts)
         piece = d_out[:max_b] if max_b <= cap else torch.cat([d_out, torch.zeros(max_b - cap, dtype=torch.uint8, device=dev)])
-        piece = piece.to(cdev)
-        got = [torch.empty(max_b, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+        piece = piece.to(coll_dev)
+        got = [torch.empty(max_b, dtype=torch.uint8, device=coll_dev) for _ in range(world)] if rank == 0 else None
         dist.gather(piece, got, dst=0)
         if rank != 0:
             return None, 0
-        whole = torch.cat([got[r][:counts[r][1]] for r in range(world)])
+        whole = torch.cat([got[r][:counts[r]] for r in range(world)])
         return whole, int(whole.numel())
 
-    once()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    whole, nbytes = once()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(route):
+        route()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        whole, nbytes = route()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, whole, nbytes
+
+    res = {"workload": "one stream of %d h of 16/44.1 stereo (%d frames) cut into %d frame ranges, one per GPU; frames brought together on rank 0 and laid end to end" % (hours, F, world),
+           "scaling": "strong", "frames_per_rank": nf, "kernel_ms_per_rank_estimate": round(nf / 38760.0 * 4.0, 2)}
+    for name, route in (("host", host_route), ("rccl", rccl_route)):
+        dt, whole, nbytes = timed(route)
+        if rank == 0:
+            crc = zlib.crc32(memoryview(whole.cpu().numpy())) & 0xffffffff
+            res[name] = {"value": round(nS / dt / 1e6, 1), "unit": "MSamples/s", "ms": round(dt * 1e3, 3), "stitched_bytes": nbytes, "stitched_crc32": "%08x" % crc}
+        del whole
+    enc.close()
     if rank != 0:
         return None
-    crc = zlib.crc32(whole.cpu().numpy().tobytes()) & 0xffffffff
-    return {"workload": "the same hour cut into %d frame ranges, coded one per GPU, sizes and bytes gathered to rank 0 and laid end to end" % world,
-            "value": round(nsamples / dt / 1e6, 1), "unit": "MSamples/s", "ms": round(dt * 1e3, 3), "stitched_bytes": nbytes, "stitched_crc32": "%08x" % crc,
-            "scaling": "strong", "includes": "encode on every rank + all_gather of counts + gather of frame bytes to rank 0 + concatenation"}
+    res["host"]["includes"] = "encode on every rank + download to page-locked memory + bytes to rank 0 over the host (gloo send/recv of exact sizes) + concatenation on the host"
+    res["rccl"]["includes"] = "encode on every rank + all_gather of sizes + gather of padded frame bytes to rank 0 over %s + concatenation on rank 0's GPU" % ("gloo (rehearsal on one GPU)" if rehearsal else "RCCL")
+    res["same_bytes"] = res["host"]["stitched_bytes"] == res["rccl"]["stitched_bytes"] and res["host"]["stitched_crc32"] == res["rccl"]["stitched_crc32"]
+    res["faster"] = "host" if res["host"]["ms"] <= res["rccl"]["ms"] else "rccl"
+    return res
 
 
 _WORK = {}
@@ -357,6 +520,8 @@ def main():
     ap.add_argument("--clips", type=int, default=10000)
     ap.add_argument("--c3-seconds", type=int, default=600)
     ap.add_argument("--c4-hours", type=int, default=8)
+    ap.add_argument("--no-sharded", action="store_true", help="skip the strong-scaling leg (one long stream cut into frame ranges)")
+    ap.add_argument("--sharded-hours", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -372,24 +537,30 @@ def main():
     _WORK["pcm32"] = np.ascontiguousarray(base.astype(np.int32))
     # CPU baseline first: its worker processes are forked before this process touches the GPU
     cpu = None
-    if not args.no_cpu_baseline and world == 1 and rank == 0:
+    if not args.no_cpu_baseline and rank == 0:
         cpu = cpu_baseline(base)
+        cpu["tool"] = cpu_tool_baselines(base)
 
     # API-level rates, in a child process of its own, before this process touches the GPU
     api = None
-    if not args.no_api and world == 1 and rank == 0:
+    if not args.no_api and rank == 0:
         api = api_rates(base, args.minutes)
 
     # rehearsal of the N > 1 path on a box with one GPU: all ranks on device 0, rendezvous and reductions over gloo
     rehearsal = os.environ.get("FLACAMD_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    host_group = None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        wait = datetime.timedelta(minutes=30)   # rank 0 measures the CPU baseline and the API rates before it joins
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=wait)
+            host_group = dist.group.WORLD
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=wait)
+            host_group = dist.new_group(backend="gloo", timeout=wait)   # the host route of the sharded leg
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local)
@@ -465,12 +636,24 @@ def main():
             del d_back
         except Exception as ex:  # reported, never hidden
             decode = {"error": str(ex)}
-    sharded = None
-    try:
-        sharded = sharded_hour(enc, d_pcm, nsamples, nframes, rank, world, dev, dist, rehearsal)
-    except Exception as ex:
-        sharded = {"error": "%s: %s" % (type(ex).__name__, ex)}
     del d_out, d_fb
+    enc.close()
+    del d_pcm
+    torch.cuda.empty_cache()
+    sharded = None
+    if not args.no_sharded:
+        try:
+            sharded = sharded_stream(base, params, rank, world, local, dev, dist, host_group, rehearsal, args.sharded_hours)
+        except Exception as ex:
+            sharded = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        torch.cuda.empty_cache()
+    # the in-process route a libFLAC client takes on a node: ONE encoder object over all N GPUs (flacamd_pipe lanes),
+    # measured by rank 0's child process while the other ranks wait at the barrier below
+    pipe = None
+    if world > 1 and rank == 0 and not args.no_api:
+        pipe = api_rates(base, args.minutes, ndev=1 if rehearsal else world)
+    if world > 1:
+        dist.barrier()
     configs = None
     if rank == 0 and world == 1 and not args.no_configs:
         configs = {}
@@ -497,19 +680,21 @@ def main():
         # the whole batch (every stage sweeps the whole batch once)
         algo_bytes = nsamples * 4 + total_bytes
         achieved = algo_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(KERNEL_OF_STAGE.get(dom, dom), args.minutes, stage_ms[dom])
         line = {
             "metric": "encode MSamples/s at -8, 16/44.1 stereo",
             "value": round(value, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "flac -8 (LPC order 12, blocksize 4096, mid/side, tukey(0.5)) on %d min of 16/44.1 stereo per GPU (one seeded 60 s synthetic programme tiled %d times), PCM resident in HBM as int16" % (args.minutes, args.minutes),
+            "config": {"workload": "flac -8 (LPC order 12, blocksize 4096, mid/side, tukey(0.5)) on %d min of 16/44.1 stereo per GPU (one seeded 60 s synthetic programme tiled %d times), PCM resident in HBM as int16; "
+                                   "kernel-level figure: the stream's MD5 (one serial chain, computed on a host thread by the encoder object) and the transfers over PCIe are excluded - "
+                                   "the same hour through the libFLAC-style API with host buffers is `api_value` / `api`" % (args.minutes, args.minutes),
                        "frames_per_gpu": nframes, "wide_samples_per_gpu": nsamples, "parallelism": "frame ranges x%d" % world,
                        "launch": "steps queued back to back on one stream (flacamd_encode_device_queue), sizes and status read by flacamd_encoder_wait in groups of up to %d" % QUEUE_DEPTH,
                        "compressed_bytes_per_gpu": total_bytes, "ratio": round(total_bytes / (nsamples * 4), 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "limited_by": "integer VALU issue (see note)", "kernel": KERNEL_OF_STAGE.get(dom, dom), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(KERNEL_OF_STAGE.get(dom, dom), args.minutes),
-                         "traffic_source": "committed rocprofv3 PMC passes of this command (profiles/r2_pmc_summary.json), not measured in this run",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer VALU-bound kernel: ~(order+5) lane-ops per sample per LPC candidate, so the HBM fraction is small by nature; stage_ms has the per-stage times"},
         }
@@ -519,10 +704,20 @@ def main():
             line["size_delta_vs_ref"] = round(size_delta, 6)
         if sharded is not None:
             line["sharded"] = sharded
+        tool = (cpu or {}).get("tool") or {}
         if configs is not None:
+            for name in ("c3", "c4_decode", "c5_clips"):   # the reference's number beside each GPU number
+                if name in configs and name in tool:
+                    configs[name]["cpu_baseline"] = tool[name]
             line["configs"] = configs
         if api is not None:
             line["api"] = api
+            if isinstance(api.get("stream_md5_on"), (int, float)):
+                # the headline workload as a client of the unchanged API sees it with the reference's defaults (MD5 on)
+                line["api_value"] = api["stream_md5_on"]
+                line["api_value_note"] = "FLAC__stream_encoder_process_interleaved from pageable host memory to a write callback, MD5 on (the reference's default), one GPU; MSamples/s"
+        if pipe is not None:
+            line["pipe"] = dict(pipe, note="one encoder object over %d GPU(s) from one process (flacamd_stream_encoder_set_devices / flacamd_pipe lanes), host buffers in, write callback out" % pipe.get("devices", 0))
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -14,9 +14,8 @@ static const uint32_t md5_k[64] = {
 	0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
 	0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
 /* One 64-byte block (RFC 1321): 64 steps in four rounds of 16; step i mixes word md5_word(i) of the block with
- * md5_k[i] into the running state through the round's boolean function and a left rotation by md5_rot(i).  The
- * loops have constant trip counts and are unrolled by the compiler (the state rotates through a, b, c, d by
- * renaming), which leaves the chain of 64 dependent steps that bounds a single stream. */
+ * md5_k[i] into the running state through the round's boolean function and a left rotation.  The state rotates
+ * through a, b, c, d by renaming, which leaves the chain of 64 dependent steps that bounds a single stream. */
 static inline uint32_t md5_rotl(uint32_t v, unsigned s) { return v << s | v >> (32u - s); }
 static inline uint32_t md5_mix(unsigned round, uint32_t b, uint32_t c, uint32_t d)
 {
@@ -32,21 +31,23 @@ static void md5_block(md5_state *m, const uint8_t *p)
 	static const uint8_t rot[4][4] = { { 7, 12, 17, 22 }, { 5, 9, 14, 20 }, { 4, 11, 16, 23 }, { 6, 10, 15, 21 } };
 	static const uint8_t first[4] = { 0, 1, 5, 0 }, stride[4] = { 1, 5, 3, 7 };   /* word of step j of round r: (first + j * stride) mod 16 */
 	uint32_t w[16], a = m->h[0], b = m->h[1], c = m->h[2], d = m->h[3];
-	unsigned r, j;
 #if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
 	memcpy(w, p, 64);
 #else
-	for(j = 0; j < 16; j++) w[j] = (uint32_t)p[4*j] | (uint32_t)p[4*j+1] << 8 | (uint32_t)p[4*j+2] << 16 | (uint32_t)p[4*j+3] << 24;
+	{ unsigned j; for(j = 0; j < 16; j++) w[j] = (uint32_t)p[4*j] | (uint32_t)p[4*j+1] << 8 | (uint32_t)p[4*j+2] << 16 | (uint32_t)p[4*j+3] << 24; }
 #endif
-#pragma GCC unroll 4
-	for(r = 0; r < 4; r++) {
-#pragma GCC unroll 16
-		for(j = 0; j < 16; j++) {
-			const uint32_t t = a + md5_mix(r, b, c, d) + w[(first[r] + j * stride[r]) & 15u] + md5_k[16u * r + j];
-			a = d; d = c; c = b;
-			b += md5_rotl(t, rot[r][j & 3u]);
-		}
-	}
+	/* 4 x 16 steps written out through the preprocessor (no reliance on an unrolling pragma: this header is compiled by
+	 * gcc and by clang), every table index a constant */
+#define MD5_STEP_AT(r, j) { \
+		const uint32_t t = a + md5_mix((r), b, c, d) + w[(first[(r)] + (j) * stride[(r)]) & 15u] + md5_k[16u * (r) + (j)]; \
+		a = d; d = c; c = b; \
+		b += md5_rotl(t, rot[(r)][(j) & 3u]); }
+#define MD5_STEPS_4(r, j) MD5_STEP_AT(r, j) MD5_STEP_AT(r, (j) + 1) MD5_STEP_AT(r, (j) + 2) MD5_STEP_AT(r, (j) + 3)
+#define MD5_ROUND_16(r) MD5_STEPS_4(r, 0) MD5_STEPS_4(r, 4) MD5_STEPS_4(r, 8) MD5_STEPS_4(r, 12)
+	MD5_ROUND_16(0) MD5_ROUND_16(1) MD5_ROUND_16(2) MD5_ROUND_16(3)
+#undef MD5_ROUND_16
+#undef MD5_STEPS_4
+#undef MD5_STEP_AT
 	m->h[0] += a; m->h[1] += b; m->h[2] += c; m->h[3] += d;
 }
 static void md5_init(md5_state *m) { m->h[0] = 0x67452301; m->h[1] = 0xefcdab89; m->h[2] = 0x98badcfe; m->h[3] = 0x10325476; m->nbytes = 0; }
