@@ -319,6 +319,7 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 	w.fixed_psum = (p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? (uint32_t*)(b + o_fps) : (uint32_t*)0;
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.frame_shift = (uint32_t*)(b + o_fshift); w.window = (const float*)(b + o_window);
 
+	if(c.debug & 0x400000u) (void)hipMemset(w.dbg, 0, 5 * sizeof(uint64_t));   // totals of the estimate spot check start at zero
 	// CRC-16 tables (polynomial x^16 + x^15 + x^2 + 1, crc.c:77)
 	{
 		uint32_t words = 0;
@@ -867,6 +868,19 @@ extern "C" int flacamd_encode_host(flacamd_encoder *e, const void *h_pcm, int pc
 	if(h_frame_bytes) HIP_TRY(hipMemcpy(h_frame_bytes, e->d_fb_stage, (size_t)F * 4u, hipMemcpyDeviceToHost));
 	if(h_last_assignment) HIP_TRY(hipMemcpy(h_last_assignment, e->work.assignment + (F - 1), 4, hipMemcpyDeviceToHost));
 	if(h_total_bytes) *h_total_bytes = total;
+	return FLACAMD_OK;
+}
+
+// Totals of the estimate spot check (FLACAMD_DEBUG bit 22 at the time the encoder was made; k_pack.hip), optionally
+// cleared: subframes looked at, subframes whose estimate differs from the bits written, sum and maximum of the
+// differences, bits written.  (The development timestamps share these words and are not taken in the same run.)
+extern "C" int flacamd_encoder_spotcheck(flacamd_encoder *e, uint64_t out[5], int reset)
+{
+	if(!e || !out) return FLACAMD_E_INVALID_ARGUMENT;
+	if(!(e->cfg.debug & 0x400000u)) return FLACAMD_E_UNSUPPORTED;
+	if(hipSetDevice(e->device) != hipSuccess) return FLACAMD_E_DEVICE;
+	if(hipMemcpy(out, e->work.dbg, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return FLACAMD_E_DEVICE;
+	if(reset && hipMemset(e->work.dbg, 0, 5 * sizeof(uint64_t)) != hipSuccess) return FLACAMD_E_DEVICE;
 	return FLACAMD_OK;
 }
 

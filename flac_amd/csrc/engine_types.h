@@ -57,12 +57,17 @@ struct FaCfg {
 //  [16:12] shift (lpc, 0..15)
 //  [21:17] suggested Rice parameter for partition order 0
 //  [22]   64-bit prediction sum (stream_encoder.c:3597-3603)
+//  [23]   bounded: (sum of |coefficient| << (subframe bps - 1)) >> shift < 2^27, so no prediction of this candidate can
+//         reach 2^27 in magnitude on samples of this width: x - prediction does not wrap, and a thread's sixteen
+//         |residual|s add up within 32 bits.  The search kernels take |x - prediction| with the unsigned
+//         absolute-difference instruction for such candidates; the others go the reference's way step by step.
 #define FA_CAND_KIND(h)  ((h) & 1u)
 #define FA_CAND_ORDER(h) (((h) >> 1) & 63u)
 #define FA_CAND_PREC(h)  (((h) >> 7) & 31u)
 #define FA_CAND_SHIFT(h) (((h) >> 12) & 31u)
 #define FA_CAND_K(h)     (((h) >> 17) & 31u)
 #define FA_CAND_WIDE(h)  (((h) >> 22) & 1u)
+#define FA_CAND_BOUNDED(h) (((h) >> 23) & 1u)
 #define FA_CAND_PACK(kind, order, prec, shift, k, wide) \
 	((uint32_t)(kind) | ((uint32_t)(order) << 1) | ((uint32_t)(prec) << 7) | ((uint32_t)(shift) << 12) | ((uint32_t)(k) << 17) | ((uint32_t)(wide) << 22))
 

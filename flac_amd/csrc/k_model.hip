@@ -60,6 +60,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 	int shift = (int)pm1 - log2cmax - 1;
 	if(shift > 15) shift = 15; else if(shift < -16) return; // lpc.c:192-195 (return 1)
 	double error = 0.0;
+	uint32_t sum_abs = 0;   // of the quantised coefficients (each below 2^15, at most 32 of them)
 	if(shift >= 0) {
 		const float scale = (float)(1 << shift);
 #pragma unroll
@@ -69,6 +70,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
 			cw.coef((uint32_t)j, v);
+			sum_abs += (uint32_t)(v < 0 ? -v : v);
 		}
 	}
 	else {
@@ -80,11 +82,14 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
 			cw.coef((uint32_t)j, v);
+			sum_abs += (uint32_t)(v < 0 ? -v : v);
 		}
 		shift = 0;
 	}
 	const uint32_t wide = (bps + eff + lg <= 32u) ? 0u : 1u;
-	cw.emit(FA_CAND_PACK(1u, order, eff, (uint32_t)shift, rice_k, wide));
+	// |prediction| <= (sum_abs * 2^(bps - 1)) >> shift for samples of bps bits
+	const uint32_t bounded = ((((unsigned long long)sum_abs << (bps - 1u)) >> shift) < (1ull << 27)) ? 1u : 0u;
+	cw.emit(FA_CAND_PACK(1u, order, eff, (uint32_t)shift, rice_k, wide) | (bounded << 23));
 }
 
 // One Levinson step i (order i+1): updates lpc[], err; lpc.c:124-146.

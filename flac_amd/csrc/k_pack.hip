@@ -806,6 +806,19 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 		}
 		return;
 	}
+	// Development switch (FLACAMD_DEBUG bit 22), the counterpart of the reference's SPOTCHECK_ESTIMATE build
+	// (stream_encoder.c:3444-3473): every coded subframe's estimate - the number the candidates were compared on - against the
+	// bits it takes in the stream.  Totals in the debug words: subframes, those whose estimate is not the exact count, the
+	// sum and the maximum of |estimate - bits|, the bits.
+	if((c.debug & 0x400000u) && tid == 0) {
+#pragma unroll
+		for(int sc = 0; sc < NSUB; sc++) {
+			const uint32_t est = w.winner[d[sc].g].hdr[1], act = d[sc].head_bits + tot[sc];
+			const uint32_t diff = est > act ? est - act : act - est;
+			atomicAdd(&w.dbg[0], 1ull); atomicAdd(&w.dbg[1], diff ? 1ull : 0ull); atomicAdd(&w.dbg[2], (unsigned long long)diff);
+			atomicMax(&w.dbg[3], (unsigned long long)diff); atomicAdd(&w.dbg[4], (unsigned long long)act);
+		}
+	}
 	// The frame's size is known before the rest of it is written: tell the frames behind (see the look-back below)
 	const uint32_t frame_nb = ((total_bits + 7u) >> 3) + 2u;
 	if(c.direct_out && tid == 0)

@@ -39,7 +39,7 @@ struct SearchShared {
 };
 
 template<typename SUM, bool SPILL>
-__global__ void __launch_bounds__(256, 3) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
+__global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
@@ -132,7 +132,28 @@ __global__ void __launch_bounds__(256, 3) fa_search_kernel(const void *__restric
 #pragma unroll
 						for(int j = 0; j < HIST; j++) q[j] = cq[ci * HIST + j];
 						const uint32_t shift = FA_CAND_SHIFT(hdr);
-						if(FA_CAND_WIDE(hdr)) lpc_each_dispatch<MAC_WIDE>(order, xw, q, shift, accum);
+						if(!(c.debug & 0x4000u)) {
+							// |x - prediction| of every sample by one |a - b| + c on the offset difference (exact for any values, see
+							// lpc_offset_diff_each).  Narrow sums wrap at 32 bits like the reference's accumulator; wide ones are added
+							// up in 32 bits where the model stage has bounded the candidate's predictions (sixteen |residual|s below
+							// 2^28 each), else in 64 bits by a multiply-add with the factor one.
+							if(sizeof(SUM) == 4 || FA_CAND_BOUNDED(hdr)) {
+								uint32_t h32 = 0, t32 = 0;
+								auto accum_u = [&](int sidx, uint32_t db, int P) { if(sidx < P) h32 = sad_u32(db, 0x80000000u, h32); else t32 = sad_u32(db, 0x80000000u, t32); };
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, accum_u);
+								head = (SUM)h32; tail = (SUM)t32;
+							}
+							else {
+								unsigned long long h64 = 0, t64 = 0;
+								auto accum_w = [&](int sidx, uint32_t db, int P) {
+									const uint32_t m = sad_u32(db, 0x80000000u, 0u);
+									if(sidx < P) h64 += (unsigned long long)m; else t64 += (unsigned long long)m;
+								};
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, accum_w);
+								head = (SUM)h64; tail = (SUM)t64;
+							}
+						}
+						else if(FA_CAND_WIDE(hdr)) lpc_each_dispatch<MAC_WIDE>(order, xw, q, shift, accum);
 						else if(bps <= 24) lpc_each_dispatch<MAC_I24>(order, xw, q, shift, accum);
 						else lpc_each_dispatch<MAC_I32>(order, xw, q, shift, accum);
 					}

@@ -281,7 +281,9 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 		// ---- |residual| sums per finest partition.  Samples before `order` carry no residual: each
 		// sample of the chunk goes (statically) to one of three accumulators, of which thread 0 keeps
 		// only the tail, thread 1 the tail and the head, every other thread all three.
-		if(active && !(dbg & 1u)) {
+		// Every lane of a wave that holds samples goes through the sums (the lanes beyond the block's end on zeros, depositing
+		// nothing): the candidate loop below votes across the wave and reads the candidates' headers out of its lanes
+		if(__any(active ? 1 : 0) && !(dbg & 1u)) {
 			SUM accT, accH, accM;
 			auto by_residual = [&](int sidx, int32_t rv, int P) {
 				const uint32_t m = abs_u32(rv);
@@ -296,7 +298,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			};
 			auto deposit = [&](uint32_t ci) {
 				const SUM v = accT + (tid >= 1u ? accH : (SUM)0) + (tid >= 2u ? accM : (SUM)0);
-				atomicAdd(&psum[(size_t)ci * SF_ROW + part], v);
+				if(active) atomicAdd(&psum[(size_t)ci * SF_ROW + part], v);
 			};
 #define SF_LOAD_Q(ci, q) do { \
 				const int4 *q4_ = (const int4*)(cq + (ci) * HIST); \
@@ -342,7 +344,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 					const uint32_t order = FA_CAND_ORDER(chdr[ci]);
 					SUM vT = fT[4], vH = fH[4];
 					if(order == 0u) { vT = fT[0]; vH = 0; } else if(order == 1u) { vT = fT[1]; vH = fH[1]; } else if(order == 2u) { vT = fT[2]; vH = fH[2]; } else if(order == 3u) { vT = fT[3]; vH = fH[3]; }
-					atomicAdd(&psum[(size_t)ci * SF_ROW + part], vT + (tid >= 1u ? vH : (SUM)0));
+					if(active) atomicAdd(&psum[(size_t)ci * SF_ROW + part], vT + (tid >= 1u ? vH : (SUM)0));
 				}
 			}
 			if(use_dot2) {

@@ -188,6 +188,38 @@ __device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t 
 	}
 }
 
+// f(s, db, P): db = 2^31 + (prediction - x) mod 2^32 for chunk sample s under an order-P predictor.  |db - 2^31| taken on
+// unsigned words (one absolute-difference instruction against a constant) is then exactly abs() of the reference's
+// 32-bit residual x - prediction, whatever the values: an unsigned word's distance from 2^31 is the magnitude of the
+// two's complement number (word - 2^31), and that number is -(x - prediction) mod 2^32, INT_MIN included.
+// The sample itself enters the 64-bit sum as one more tap with the coefficient -2^shift and the sum starts from
+// 2^(31 + shift), a multiple of 2^shift: ((2^(31+shift) + S - x 2^shift) >> shift) = 2^31 + (S >> shift) - x, all mod 2^64,
+// and one funnel shift of the two halves yields its low word - the truncation to 32 bits of lpc.c:577-586.  Candidates
+// the reference sums in 32 bits (lpc.c:296) take this path too: it gives a candidate 32 bits only where samples and
+// coefficients of the stated widths cannot carry the sum out of them (stream_encoder.c:3597-3603: bps + precision +
+// ilog2(order) <= 32), so the exact sum is the wrapping one.
+template<int P, int W, class F>
+__device__ __forceinline__ void lpc_offset_diff_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+	const int32_t self = -(int32_t)(1u << shift);
+#pragma unroll
+	for(int s = 0; s < W - HIST; s++) {
+		long long acc = (long long)(1ull << (31u + shift));
+		acc += (long long)self * (long long)xw[HIST + s];
+#pragma unroll
+		for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+		f(s, __builtin_amdgcn_alignbit((uint32_t)((unsigned long long)acc >> 32), (uint32_t)acc, shift), P);
+	}
+}
+
+template<int W, class F>
+__device__ __forceinline__ void lpc_offset_diff_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+{
+#define RESIDUAL_CALL(P) lpc_offset_diff_each<P>(xw, q, shift, f)
+	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
+#undef RESIDUAL_CALL
+}
+
 // k-th difference, 32-bit wrapping
 template<int K, int W, class F>
 __device__ __forceinline__ void fixed_each(const int32_t (&xw)[W], F &&f)

@@ -95,6 +95,7 @@ def lib():
         L.flacamd_encode_host.argtypes = [vp, vp, C.c_int, u64, C.c_int, u32, u32, vp, sz, vp, C.POINTER(u64), C.POINTER(u32)]
         L.flacamd_encoder_debug_read.argtypes = [vp, C.c_int, vp, sz]
         L.flacamd_encoder_debug_read.restype = C.c_long
+        L.flacamd_encoder_spotcheck.argtypes = [vp, C.POINTER(u64 * 5), C.c_int]
         L.flacamd_encoder_set_timing.argtypes = [vp, C.c_int]
         L.flacamd_encoder_set_timing.restype = None
         L.flacamd_encoder_last_timing.argtypes = [vp, C.POINTER(C.c_float * 6)]
@@ -289,6 +290,14 @@ class Encoder:
         if got < 0:
             raise EngineError(got, "flacamd_encoder_debug_read")
         return buf[: got // buf.itemsize]
+
+    def spotcheck(self, reset=False):
+        """Totals of the estimate spot check (flacamd_encoder_spotcheck): subframes checked, subframes whose estimate
+        differed from the packed size, sum and maximum of the differences in bits, bits packed.  Only for an encoder
+        created with the switch 0x400000 in FLACAMD_DEBUG."""
+        out = (C.c_uint64 * 5)()
+        _check(self._lib.flacamd_encoder_spotcheck(self._h, C.byref(out), 1 if reset else 0), "flacamd_encoder_spotcheck")
+        return dict(zip(("subframes", "differing", "sum_abs_bits", "max_abs_bits", "packed_bits"), (int(v) for v in out)))
 
 
 class Pipe:

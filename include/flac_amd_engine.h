@@ -237,6 +237,14 @@ void flacamd_pcm_narrow(int16_t *dst, const int32_t *src, size_t nvalues);
  * nsignals = frames x (4 for mid/side stereo, else channels). Returns bytes written or <0. */
 long flacamd_encoder_debug_read(flacamd_encoder *e, int what, void *h_dst, size_t cap);
 
+/* The reference's SPOTCHECK_ESTIMATE build (stream_encoder.c:3444-3473: every candidate's estimated size against the
+ * bits it really takes) as a switch: an encoder made while the environment has FLACAMD_DEBUG bit 22 (0x400000) set
+ * compares, for every subframe it writes (mono / stereo streams with blocks up to 4096 samples), the winner's estimate
+ * with the bits written and adds up: out[0] subframes, out[1] subframes whose estimate is not exact, out[2] sum of
+ * |estimate - bits|, out[3] the largest difference, out[4] bits written.  reset != 0 clears the totals afterwards.
+ * FLACAMD_E_UNSUPPORTED when the encoder was made without the switch. */
+int flacamd_encoder_spotcheck(flacamd_encoder *e, uint64_t out[5], int reset);
+
 /* White-box view for parity tests: the two logarithm expressions of the model stage (fixed.c:256-268: bits expected of a
  * fixed predictor from its |residual| sum e over len samples; lpc.c:1336-1351: bits expected of an LPC order from its
  * prediction error and scale), evaluated on the device for n inputs of the caller's choosing. */

@@ -23,3 +23,13 @@ def test_seeded_random_configurations_match_the_oracle(gpu_engine, first):
         assert r[0], r[1]
         ran += 1
     assert ran >= 25
+
+
+# Seeds on which a development build once differed from the oracle: blocks shorter than the 4096 samples a search
+# workgroup covers (2304, 1152, 192, 16 samples: waves with lanes beyond the block's end, down to a single lane with
+# samples), where the candidate loop's votes across the wave must still see every candidate.
+@pytest.mark.parametrize("seed", [300077, 300186, 300284, 301107, 301932, 302579, 302919, 303187, 303692, 304242, 304850, 305270, 305523])
+def test_seeds_that_once_differed(gpu_engine, seed):
+    import parity_fuzz
+    r = parity_fuzz.run_seed(seed)
+    assert r is not None and r[0], r

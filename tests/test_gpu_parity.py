@@ -256,6 +256,41 @@ def test_alternative_stage_arrangements_give_the_same_frames(gpu_engine, monkeyp
         assert frames == want and alt == want
 
 
+def test_estimate_spot_check_totals(gpu_engine, monkeypatch):
+    """The development switch 0x400000 has the pack kernel compare each chosen subframe's estimated size with the bits
+    it packs (the reference's SPOTCHECK_ESTIMATE, stream_encoder.c:3444-3473).  Constant subframes are estimated
+    exactly; Rice-coded ones by the reference's approximation (stream_encoder.c:3862-3876), which must stay within a
+    small fraction of the packed size.  The frames themselves do not change, and an encoder created without the
+    switch refuses the query."""
+    from flac_amd import synth
+    music = synth.music_like(3.0, seed=17).astype(np.int16)[: 32 * 4096]
+    silence = np.zeros((3 * 4096, 2), dtype=np.int16)
+    plain, (want, _) = _encode(gpu_engine, 2, 16, 44100, dict(level=8), music)
+    try:
+        with pytest.raises(gpu_engine.EngineError):
+            plain.spotcheck()
+    finally:
+        plain.close()
+    monkeypatch.setenv("FLACAMD_DEBUG", "0x400000")
+    try:
+        e, (got, _) = _encode(gpu_engine, 2, 16, 44100, dict(level=8), music)
+        try:
+            t = e.spotcheck(reset=True)
+            assert got == want
+            assert t["subframes"] == 2 * len(got)
+            payload = 8 * sum(len(f) for f in got)
+            assert 0.97 * payload < t["packed_bits"] <= payload
+            assert t["sum_abs_bits"] < 0.01 * t["packed_bits"] and t["max_abs_bits"] < 0.05 * t["packed_bits"] / t["subframes"]
+            assert e.spotcheck()["subframes"] == 0, "reset"
+            frames, _ = e.encode_host(silence)
+            t = e.spotcheck()
+            assert t["subframes"] == 2 * len(frames) and t["differing"] == 0
+        finally:
+            e.close()
+    finally:
+        monkeypatch.delenv("FLACAMD_DEBUG")
+
+
 @pytest.mark.parametrize("channels", [2, 3])
 def test_output_buffer_too_small_is_reported(gpu_engine, channels):
     """Frames that do not fit the caller's buffer are not written past its end: the call reports the capacity error

@@ -3,6 +3,7 @@
 // 256 CUs x 8 waves/SIMD.  Prints wave-instructions per cycle-equivalent (ns per instr per SIMD).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #define ITERS 2048
@@ -37,13 +38,11 @@ __global__ void __launch_bounds__(256) NAME(int *out, int a, int b) { \
 #define A_PERM(x) "v_perm_b32 " #x ", %8, " #x ", %9"
 #define A_BFE(x) "v_bfe_i32 " #x ", " #x ", 3, 16"
 #define A_MOV(x) "v_mov_b32 " #x ", %8"
-#define A_CNDMASK(x) "v_cndmask_b32 " #x ", %8, " #x ", vcc"
 #define A_XOR(x) "v_xor_b32 " #x ", %8, " #x
 DEF_KERNEL(k_alignbit, A_ALIGNBIT)
 DEF_KERNEL(k_perm, A_PERM)
 DEF_KERNEL(k_bfe, A_BFE)
 DEF_KERNEL(k_mov, A_MOV)
-DEF_KERNEL(k_cndmask, A_CNDMASK)
 DEF_KERNEL(k_xor, A_XOR)
 DEF_KERNEL(k_mad24, A_MAD24)
 DEF_KERNEL(k_mul24, A_MUL24)
@@ -97,6 +96,25 @@ DEF_KERNEL64(k_pkaddf, A_PKADDF)
 DEF_KERNEL64(k_pkfmaf, A_PKFMAF)
 DEF_KERNEL64(k_fma64, A_FMA64)
 
+// The shader clock while every SIMD is busy with the multiply-add loop: the shader clock counter (s_memtime) against the
+// constant 100 MHz counter (s_memrealtime) over the same stretch, read by the first lane of every workgroup.  The "cycles"
+// column below converts with this measured frequency, not with a nominal one.
+__global__ void __launch_bounds__(256) k_clock(int *out, int a, int b, unsigned long long *ticks)
+{
+	int x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+	int va = a + threadIdx.x, vb = b ^ threadIdx.x;
+	const unsigned long long c0 = clock64(), r0 = wall_clock64();
+	for(int i = 0; i < ITERS * 4; i++) {
+		asm volatile(A_MAD24(%0) "\n" A_MAD24(%1) "\n" A_MAD24(%2) "\n" A_MAD24(%3) "\n" A_MAD24(%4) "\n" A_MAD24(%5) "\n" A_MAD24(%6) "\n" A_MAD24(%7)
+			: "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(va), "v"(vb));
+	}
+	const unsigned long long c1 = clock64(), r1 = wall_clock64();
+	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+	if(threadIdx.x == 0) { ticks[2 * blockIdx.x] = c1 - c0; ticks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+static double g_ghz = 2.4;
+
 template<typename K, typename T>
 static void run(const char *name, K kern, T *buf)
 {
@@ -111,18 +129,34 @@ static void run(const char *name, K kern, T *buf)
 	float ms; hipEventElapsedTime(&ms, e0, e1);
 	// wave-instructions per SIMD: 8 waves x ITERS x 8
 	const double per_simd = 8.0 * ITERS * 8.0;
-	printf("%-12s %8.3f ms  %6.2f ns per wave-instr per SIMD  (= %5.2f cycles at 2.4 GHz)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+	printf("%-12s %8.3f ms  %6.2f ns per wave-instr per SIMD  (= %5.2f cycles at the measured %.3f GHz)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * g_ghz, g_ghz);
 }
 
 int main()
 {
 	int *buf; hipMalloc(&buf, 256 * 8 * 256 * 8);
+	{
+		const int blocks = 256 * 8;
+		unsigned long long *d_ticks, *h_ticks = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * blocks);
+		hipMalloc(&d_ticks, sizeof(unsigned long long) * 2 * blocks);
+		hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, buf, 3, 5, d_ticks);
+		hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, buf, 3, 5, d_ticks);
+		hipMemcpy(h_ticks, d_ticks, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
+		double lo = 1e30, hi = 0, sum = 0;
+		for(int i = 0; i < blocks; i++) {
+			const double ghz = (double)h_ticks[2 * i] / ((double)h_ticks[2 * i + 1] / 0.1);   // shader ticks per ns: the constant counter runs at 100 MHz
+			lo = ghz < lo ? ghz : lo; hi = ghz > hi ? ghz : hi; sum += ghz;
+		}
+		g_ghz = sum / blocks;
+		printf("shader clock under an all-SIMD integer multiply-add load: mean %.3f GHz (min %.3f, max %.3f over %d workgroups; s_memtime ticks per s_memrealtime tick x 100 MHz)\n", g_ghz, lo, hi, blocks);
+		hipFree(d_ticks); free(h_ticks);
+	}
 	run("mad_i32_i24", k_mad24, buf); run("mul_i32_i24", k_mul24, buf); run("mad_u32_u24", k_madu24, buf); run("add_u32", k_add, buf); run("add3_u32", k_add3, buf);
 	run("mul_lo_u32", k_mullo, buf); run("dot2_i32_i16", k_dot2, buf); run("dot4_i32_i8", k_dot4, buf); run("sad_u32", k_sad, buf);
 	run("max_i32", k_maxi, buf); run("fma_f32", k_fma, buf); run("mul_f32", k_mulf, buf); run("mad_i32_i16", k_madi16, buf); run("pk_mad_i16", k_pkmad, buf);
 	run("ashrrev_i32", k_ashr, buf); run("lshl_add_u32", k_lshladd, buf);
 	run("mad_i64_i32", k_mad64, (long long*)buf);
-	run("alignbit_b32", k_alignbit, buf); run("perm_b32", k_perm, buf); run("bfe_i32", k_bfe, buf); run("mov_b32", k_mov, buf); run("cndmask_b32", k_cndmask, buf); run("xor_b32", k_xor, buf);
+	run("alignbit_b32", k_alignbit, buf); run("perm_b32", k_perm, buf); run("bfe_i32", k_bfe, buf); run("mov_b32", k_mov, buf); run("xor_b32", k_xor, buf);
 	run("ashrrev_i64", k_ashr64, (long long*)buf); run("lshl_add_u64", k_lshladd64, (long long*)buf);
 	run("pk_mul_f32", k_pkmulf, (long long*)buf); run("pk_add_f32", k_pkaddf, (long long*)buf); run("pk_fma_f32", k_pkfmaf, (long long*)buf); run("fma_f64", k_fma64, (long long*)buf);
 	return 0;
