@@ -279,15 +279,16 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 	}
 	{ const char *dbg = getenv("FLACAMD_DEBUG"); c.debug = dbg ? (uint32_t)strtoul(dbg, 0, 0) : 0u; }
 	c.spill = p.blocksize > FA_LDS_BLOCKSIZE ? 1u : 0u;
-	// all candidates in one round where they are few; else sixteen at a time: with the signal that is 38 KB of LDS, four workgroups per CU
-	e->cand_group = c.max_cand <= 24u ? c.max_cand : 16u;
+	// all candidates in one round where they are few; else thirty-two at a time (eight lanes price a candidate: a full workgroup):
+	// with the signal that is 38 KB of LDS, four workgroups per CU
+	e->cand_group = c.max_cand <= 24u ? c.max_cand : 32u;
 	if(e->cand_group == 0) e->cand_group = 1;
 	e->sum64 = (ilog2u(p.blocksize) + p.bits_per_sample + 1u < 32u) ? 0 : 1;
 	// LDS of the general kernels: fewer candidates per pass, then the signal out of LDS, until a workgroup's tables fit
 	while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
 	if((fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u || fa_pack_lds_bytes(&c, 0) > 160u * 1024u) && !c.spill) {
 		c.spill = 1u;
-		e->cand_group = c.max_cand <= 24u ? (c.max_cand ? c.max_cand : 1u) : 16u;
+		e->cand_group = c.max_cand <= 24u ? (c.max_cand ? c.max_cand : 1u) : 32u;
 		while(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u && e->cand_group > 1u) e->cand_group = (e->cand_group + 1u) / 2u;
 	}
 	if(fa_search_lds_bytes(&c, e->cand_group) > 160u * 1024u) { free(e); return FLACAMD_E_UNSUPPORTED; }
@@ -296,7 +297,7 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 	// one arena for all per-batch arrays
 	const size_t G = (size_t)max_frames * c.nsig, F = max_frames;
 	const size_t qrows = p.max_lpc_order ? p.max_lpc_order : 1u;
-	c.cand_stride = (uint32_t)((1u + qrows + 3u) & ~(size_t)3u);
+	c.cand_stride = (uint32_t)((2u + qrows + 3u) & ~(size_t)3u);   // header, coefficients, their sum
 	size_t off = 0;
 	auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
 	const size_t o_wasted = take(G), o_const = take(G), o_ferr = take(5 * G * 8), o_autoc = take((size_t)c.num_apod * c.lag * G * 4),

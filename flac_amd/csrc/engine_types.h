@@ -40,7 +40,7 @@ struct FaCfg {
 	uint32_t num_apod;
 	uint32_t lag;             // max_lpc_order + 1
 	uint32_t max_cand;        // candidate slots per signal
-	uint32_t cand_stride;     // dwords per candidate record: header + coefficients, rounded to a multiple of 4
+	uint32_t cand_stride;     // dwords per candidate record: header + max(max_lpc_order, 1) coefficients + their sum, rounded up to a multiple of 4
 	uint32_t k_limit;         // 15, or 31 when stream bps > 16 (stream_encoder.c:3200)
 	uint32_t wide_fixed;      // 64-bit fixed-predictor error sums (stream_encoder.c:894)
 	uint32_t slot_bytes;      // bytes reserved per frame in the slot buffer (multiple of 16)
@@ -113,7 +113,8 @@ struct FaWork {
 	// model
 	uint32_t *ncand;       // [G]
 	// candidate records, one signal's records contiguous: [G][max_cand][cand_stride] dwords, each record
-	// = header word then the coefficients; cand_q points one dword past cand_hdr so that both index alike
+	// = header word, the coefficients (max(max_lpc_order, 1) rows), then the sum of the coefficients of a linear
+	// predictor; cand_q points one dword past cand_hdr so that both index alike
 	uint32_t *cand_hdr;
 	int32_t  *cand_q;
 	// search

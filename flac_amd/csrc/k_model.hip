@@ -21,7 +21,7 @@
 #define FA_LN2 0.69314718055994530942
 
 struct CandWriter {
-	uint32_t *hdr; int32_t *q; uint32_t stride, n, max_cand;   // hdr / q already offset to this signal's records
+	uint32_t *hdr; int32_t *q; uint32_t stride, n, max_cand, qrows;   // hdr / q already offset to this signal's records; qrows: row of the coefficient sum
 	__device__ __forceinline__ void emit(uint32_t h) { if(n < max_cand) hdr[(size_t)n * stride] = h; n++; }
 	__device__ __forceinline__ void coef(uint32_t j, int32_t v) { if(n < max_cand) q[(size_t)n * stride + j] = v; }
 };
@@ -61,6 +61,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 	if(shift > 15) shift = 15; else if(shift < -16) return; // lpc.c:192-195 (return 1)
 	double error = 0.0;
 	uint32_t sum_abs = 0;   // of the quantised coefficients (each below 2^15, at most 32 of them)
+	int32_t sum_q = 0;
 	if(shift >= 0) {
 		const float scale = (float)(1 << shift);
 #pragma unroll
@@ -70,7 +71,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
 			cw.coef((uint32_t)j, v);
-			sum_abs += (uint32_t)(v < 0 ? -v : v);
+			sum_abs += (uint32_t)(v < 0 ? -v : v); sum_q += v;
 		}
 	}
 	else {
@@ -82,13 +83,14 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
 			cw.coef((uint32_t)j, v);
-			sum_abs += (uint32_t)(v < 0 ? -v : v);
+			sum_abs += (uint32_t)(v < 0 ? -v : v); sum_q += v;
 		}
 		shift = 0;
 	}
 	const uint32_t wide = (bps + eff + lg <= 32u) ? 0u : 1u;
 	// |prediction| <= (sum_abs * 2^(bps - 1)) >> shift for samples of bps bits
 	const uint32_t bounded = ((((unsigned long long)sum_abs << (bps - 1u)) >> shift) < (1ull << 27)) ? 1u : 0u;
+	cw.coef(cw.qrows, sum_q);
 	cw.emit(FA_CAND_PACK(1u, order, eff, (uint32_t)shift, rice_k, wide) | (bounded << 23));
 }
 
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(64) fa_model_kernel(FaCfg c, FaWork w)
 	const uint32_t wasted = w.wasted[g];
 	const uint32_t bps = c.bps - wasted + ((c.midside && s == 3u) ? 1u : 0u);
 
-	CandWriter cw; cw.hdr = w.cand_hdr + fa_cand_idx(c, g, 0); cw.q = w.cand_q + fa_cand_idx(c, g, 0); cw.stride = c.cand_stride; cw.n = 0; cw.max_cand = c.max_cand;
+	CandWriter cw; cw.hdr = w.cand_hdr + fa_cand_idx(c, g, 0); cw.q = w.cand_q + fa_cand_idx(c, g, 0); cw.stride = c.cand_stride; cw.n = 0; cw.max_cand = c.max_cand; cw.qrows = c.max_lpc_order ? c.max_lpc_order : 1u;
 
 	const bool constant = (!c.disable_constant) && (w.is_const[g] & 1u);
 	if(n >= FA_MAX_FIXED_ORDER && !constant) {

@@ -25,6 +25,7 @@
 #include "engine_types.h"
 #include "residual.h"
 #include "wave_ops.h"
+#include "search_price.h"
 
 // format.c:548-561
 __device__ __forceinline__ uint32_t limit_po(uint32_t limit, uint32_t blocksize, uint32_t order)
@@ -33,13 +34,29 @@ __device__ __forceinline__ uint32_t limit_po(uint32_t limit, uint32_t blocksize,
 	return limit;
 }
 
+// Candidates per LDS round.  Blocks priced by the lanes of a wave (sp_price_group) keep SP_ROW sums per candidate and take
+// `cg` candidates at a time; the others keep the sums of every partition order (2 * parts_cap entries) and take as many
+// candidates as fit the same LDS.
+__host__ __device__ __forceinline__ uint32_t search_cg_rows(uint32_t cg, uint32_t parts_cap)
+{
+	const uint32_t prow = 2u * parts_cap;
+	if(prow <= SP_ROW) return cg;
+	const uint32_t m = cg * SP_ROW / prow;
+	return m ? m : 1u;
+}
+__host__ __device__ __forceinline__ uint32_t search_psum_entries(uint32_t cg, uint32_t parts_cap)
+{
+	const uint32_t a = cg * SP_ROW, b = search_cg_rows(cg, parts_cap) * 2u * parts_cap;
+	return a > b ? a : b;
+}
+
 struct SearchShared {
 	uint32_t best_est, best_cand, best_po, have_best;
 	uint32_t rice2, group_won;
 };
 
 template<typename SUM, bool SPILL>
-__global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg, uint32_t g0)
+__global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t cg_arg, uint32_t g0)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
@@ -60,6 +77,8 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 	const uint32_t minpo_f = c.min_po < maxpo_f ? c.min_po : maxpo_f;
 	const uint32_t parts0 = 1u << maxpo_f, dps0 = n >> maxpo_f;
 	const bool fast = ((n & (CH - 1)) == 0) && ((dps0 & (CH - 1)) == 0);
+	// the evaluation phase by lanes of a wave (at most 64 finest partitions), or over (candidate, order, partition) items
+	const bool wprice = fast && maxpo_f <= 6u && !(c.debug & 0x800000u);
 
 	// LDS carve-up
 	// the workgroup's copy of the signal: in LDS, or for blocks too long for that in this signal's row of the spill buffer
@@ -71,15 +90,21 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 	// (parts0 entries), then each coarser order, 2*parts0 - 1 entries in all
 	unsigned long long *psum = (unsigned long long*)(lds_raw + (((size_t)xs_words * 4u + 15u) & ~(size_t)15u)); // [cg][2 * parts_cap]
 	const uint32_t parts_cap = 1u << (c.max_po < FLACAMD_MAX_PARTITION_ORDER ? c.max_po : FLACAMD_MAX_PARTITION_ORDER);
-	const uint32_t prow = 2u * parts_cap;
-	uint32_t *lbits = (uint32_t*)(psum + (size_t)cg * prow);                      // [cg][16]
-	unsigned long long *ckey = (unsigned long long*)(lbits + (size_t)cg * 16u);    // [cg]
-	uint32_t *cpo = (uint32_t*)(ckey + cg);                                        // [cg]
-	uint8_t *kbuf = (uint8_t*)(cpo + cg);                                          // [cg][2*parts_cap]
-	uint8_t *best_k = kbuf + (size_t)cg * 2u * parts_cap;                          // [parts_cap]
+	const uint32_t prow = wprice ? SP_ROW : 2u * parts_cap;
+	const uint32_t cg = wprice ? cg_arg : search_cg_rows(cg_arg, parts_cap);      // candidates per round of this block
+	const uint32_t psum_entries = search_psum_entries(cg_arg, parts_cap);
+	uint32_t *lbits = (uint32_t*)(psum + psum_entries);                           // [cg][16]
+	unsigned long long *ckey = (unsigned long long*)(lbits + (size_t)cg_arg * 16u);    // [cg]
+	uint32_t *cpo = (uint32_t*)(ckey + cg_arg);                                    // [cg]
+	uint8_t *kbuf = (uint8_t*)(cpo + cg_arg);                                      // [cg][2*parts_cap] (not kept by the wave pricing)
+	uint8_t *best_k = kbuf + psum_entries;                                         // [parts_cap]
 	uint32_t *chdr = (uint32_t*)(lds_raw + (((size_t)(best_k + parts_cap - lds_raw) + 3u) & ~(size_t)3u));                              // [cg] candidate headers of the current group
-	int32_t *cq = (int32_t*)(chdr + cg);                                           // [cg][HIST] coefficients (orders <= HIST)
-	uint32_t *cinfo = (uint32_t*)(cq + (size_t)cg * HIST);                         // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
+	int32_t *cq = (int32_t*)(chdr + cg_arg);                                       // [cg][HIST] coefficients (orders <= HIST)
+	uint32_t *cinfo = (uint32_t*)(cq + (size_t)cg_arg * HIST);                     // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
+	int32_t *cqsum = (int32_t*)(cinfo + cg_arg);                                   // [cg] sum of the candidate's coefficients (orders <= HIST)
+	// The register windows hold the samples plus this constant where that keeps every sample positive and below 2^31
+	// (lpc_biased_pred_each); fixed predictors of order >= 1 are differences and do not see it
+	const uint32_t bias = (bps <= 26u && !(c.debug & 0x4000u)) ? 0x40000000u : 0u;
 
 	// ---- stage the signal: xs[-32..-1] = 0, xs[0..n) = signal >> wasted, zero up to the next chunk boundary
 	if(tid == 0) { sh.have_best = 0; sh.best_est = 0; sh.best_cand = 0xffffffffu; sh.best_po = 0; sh.rice2 = 0; }
@@ -94,10 +119,15 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 
 	for(uint32_t cb = 0; cb < ncand; cb += cg) {
 		const uint32_t gn = (ncand - cb) < cg ? (ncand - cb) : cg;
-		for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * prow + (t % parts0)] = 0;
+		if(wprice) { for(uint32_t t = tid; t < gn * SP_ROW; t += 256) psum[t] = 0; }
+		else for(uint32_t t = tid; t < gn * parts0; t += 256) psum[(size_t)(t / parts0) * prow + (t % parts0)] = 0;
 		for(uint32_t t = tid; t < gn * 16u; t += 256) lbits[t] = 0;
 		// candidate headers and coefficients of this group: one parallel fetch into LDS
-		for(uint32_t t = tid; t < gn; t += 256) chdr[t] = w.cand_hdr[fa_cand_idx(c, g, (cb + t))];
+		for(uint32_t t = tid; t < gn; t += 256) {
+			const size_t rec = fa_cand_idx(c, g, (cb + t));
+			chdr[t] = w.cand_hdr[rec];
+			cqsum[t] = w.cand_q[rec + qrows];   // sum of the coefficients (linear predictors; not read for others)
+		}
 		for(uint32_t t = tid; t < gn * HIST; t += 256) {
 			const uint32_t ci = t / HIST, j = t - ci * HIST;
 			cq[t] = (j < qrows) ? w.cand_q[fa_cand_idx(c, g, (cb + ci)) + j] : 0;
@@ -119,28 +149,37 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 			for(uint32_t chunk = tid; chunk * CH < n; chunk += 256) {
 				int32_t xw[HIST + CH];
 #pragma unroll
-				for(int j = 0; j < HIST + CH; j++) xw[j] = xs[xs_idx((int32_t)(chunk * CH) - HIST + j)];
+				for(int j = 0; j < HIST + CH; j++) xw[j] = (int32_t)((uint32_t)xs[xs_idx((int32_t)(chunk * CH) - HIST + j)] + bias);
 				const uint32_t part = chunk / cpp;
 				for(uint32_t ci = 0; ci < gn; ci++) {
 					const uint32_t hdr = chdr[ci];
 					const uint32_t order = FA_CAND_ORDER(hdr);
 					SUM head = 0, tail = 0;
 					auto accum = [&](int sidx, int32_t rv, int P) { const uint32_t m = abs_u32(rv); if(sidx < P) head += m; else tail += m; };
-					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, accum);
+					auto accum_fixed = [&](int sidx, int32_t rv, int P) { accum(sidx, P == 0 ? (int32_t)((uint32_t)rv - bias) : rv, P); };
+					if(FA_CAND_KIND(hdr) == 0) fixed_each_dispatch(order, xw, accum_fixed);
 					else if(order <= HIST) {
 						int32_t q[HIST];
 #pragma unroll
 						for(int j = 0; j < HIST; j++) q[j] = cq[ci * HIST + j];
 						const uint32_t shift = FA_CAND_SHIFT(hdr);
 						if(!(c.debug & 0x4000u)) {
-							// |x - prediction| of every sample by one |a - b| + c on the offset difference (exact for any values, see
-							// lpc_offset_diff_each).  Narrow sums wrap at 32 bits like the reference's accumulator; wide ones are added
-							// up in 32 bits where the model stage has bounded the candidate's predictions (sixteen |residual|s below
-							// 2^28 each), else in 64 bits by a multiply-add with the factor one.
-							if(sizeof(SUM) == 4 || FA_CAND_BOUNDED(hdr)) {
+							// |x - prediction| of every sample by one |a - b| + c.  Where the model stage has bounded the candidate's
+							// predictions (below 2^27: sixteen |residual|s cannot carry out of 32 bits) and the window is biased, on the
+							// biased sample and prediction; else on the offset difference (exact for any values, see
+							// lpc_offset_diff_each), added up in 32 bits for narrow sums - they wrap like the reference's
+							// accumulator - and in 64 bits for wide ones.
+							const long long qs = (long long)cqsum[ci], b64 = (long long)bias;
+							if(bias && FA_CAND_BOUNDED(hdr)) {
+								uint32_t h32 = 0, t32 = 0;
+								auto accum_b = [&](int sidx, uint32_t pb, int P) { if(sidx < P) h32 = sad_u32((uint32_t)xw[HIST + sidx], pb, h32); else t32 = sad_u32((uint32_t)xw[HIST + sidx], pb, t32); };
+								lpc_biased_pred_each_dispatch(order, xw, q, shift, (b64 << shift) - b64 * qs, accum_b);
+								head = (SUM)h32; tail = (SUM)t32;
+							}
+							else if(sizeof(SUM) == 4 || FA_CAND_BOUNDED(hdr)) {
 								uint32_t h32 = 0, t32 = 0;
 								auto accum_u = [&](int sidx, uint32_t db, int P) { if(sidx < P) h32 = sad_u32(db, 0x80000000u, h32); else t32 = sad_u32(db, 0x80000000u, t32); };
-								lpc_offset_diff_each_dispatch(order, xw, q, shift, accum_u);
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, (long long)(1ull << (31u + shift)) - b64 * (qs - (1ll << shift)), accum_u);
 								head = (SUM)h32; tail = (SUM)t32;
 							}
 							else {
@@ -149,7 +188,7 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 									const uint32_t m = sad_u32(db, 0x80000000u, 0u);
 									if(sidx < P) h64 += (unsigned long long)m; else t64 += (unsigned long long)m;
 								};
-								lpc_offset_diff_each_dispatch(order, xw, q, shift, accum_w);
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, (long long)(1ull << (31u + shift)) - b64 * (qs - (1ll << shift)), accum_w);
 								head = (SUM)h64; tail = (SUM)t64;
 							}
 						}
@@ -195,6 +234,28 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 			}
 		}
 		__syncthreads();
+
+		if(wprice) {
+			// ---- eight lanes price a candidate at every partition order; the first wave keeps the best of the group
+			// (ordered arg-min: estimate, then candidate index) and works out the Rice parameters of a new leader
+			if(!(c.debug & 2u)) sp_price_group(psum, chdr, cinfo, ckey, cpo, gn, cb, tid, 256u, maxpo_f, dps0, wasted, bps, c.k_limit);
+			__syncthreads();
+			if(tid < 64u && !(c.debug & 2u)) {
+				unsigned long long bk = (tid < gn) ? ckey[tid] : ~0ull;
+#pragma unroll
+				for(int o = 32; o > 0; o >>= 1) { const unsigned long long t = (unsigned long long)__shfl_xor((long long)bk, o, 64); bk = t < bk ? t : bk; }
+				const uint32_t est = (uint32_t)(bk >> 32), widx = (uint32_t)bk - cb;
+				// earlier groups hold earlier candidates: replace only when strictly smaller
+				if(!sh.have_best || est < sh.best_est) {
+					const uint32_t po = cpo[widx], lv = maxpo_f - po;
+					const uint32_t kw = sp_winner_parameters(psum + (size_t)widx * SP_ROW, cinfo[widx], chdr[widx], tid, maxpo_f, n, po, c.k_limit);
+					if(tid < parts0 && (tid & ((1u << lv) - 1u)) == 0u) best_k[tid >> lv] = (uint8_t)kw;
+					if(tid == 0) { sh.have_best = 1; sh.best_est = est; sh.best_cand = cb + widx; sh.best_po = po; }
+				}
+			}
+			__syncthreads();
+			continue;
+		}
 
 		// ---- sums of the coarser partition orders: pairwise merges, three orders per barrier.
 		// A value read at the candidate's own finest order is first wrapped to 32 bits when the
@@ -353,17 +414,19 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 {
 	const size_t xs_words = c->spill ? 0u : xs_words_for(c->N);
 	const size_t parts_cap = (size_t)1 << (c->max_po < FLACAMD_MAX_PARTITION_ORDER ? c->max_po : FLACAMD_MAX_PARTITION_ORDER);
+	const size_t entries = search_psum_entries(cg, (uint32_t)parts_cap);
 	size_t b = (xs_words * 4u + 15u) & ~(size_t)15u;
-	b += (size_t)cg * 2u * parts_cap * 8u;  // psum, all partition orders
+	b += entries * 8u;                 // psum: SP_ROW sums per candidate, or those of all partition orders for fewer candidates
 	b += (size_t)cg * 16u * 4u;        // lbits
 	b += (size_t)cg * 8u;              // ckey
 	b += (size_t)cg * 4u;              // cpo
-	b += (size_t)cg * 2u * parts_cap;  // kbuf
+	b += entries;                      // kbuf
 	b += parts_cap;                    // best_k
 	b = (b + 3u) & ~(size_t)3u;
 	b += (size_t)cg * 4u;              // chdr
 	b += (size_t)cg * HIST * 4u;       // cq
 	b += (size_t)cg * 4u;              // cinfo
+	b += (size_t)cg * 4u;              // cqsum
 	return (b + 15u) & ~(size_t)15u;
 }
 

@@ -198,13 +198,15 @@ __device__ __forceinline__ void lpc_each_dispatch(uint32_t order, const int32_t 
 // the reference sums in 32 bits (lpc.c:296) take this path too: it gives a candidate 32 bits only where samples and
 // coefficients of the stated widths cannot carry the sum out of them (stream_encoder.c:3597-3603: bps + precision +
 // ilog2(order) <= 32), so the exact sum is the wrapping one.
+// The window may hold the samples plus a constant b (see lpc_biased_pred_each): the caller then starts the sum from
+// init = 2^(31 + shift) - b (sum of the coefficients - 2^shift), which takes the constant out of every tap.
 template<int P, int W, class F>
-__device__ __forceinline__ void lpc_offset_diff_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+__device__ __forceinline__ void lpc_offset_diff_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, long long init, F &&f)
 {
 	const int32_t self = -(int32_t)(1u << shift);
 #pragma unroll
 	for(int s = 0; s < W - HIST; s++) {
-		long long acc = (long long)(1ull << (31u + shift));
+		long long acc = init;
 		acc += (long long)self * (long long)xw[HIST + s];
 #pragma unroll
 		for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
@@ -213,9 +215,35 @@ __device__ __forceinline__ void lpc_offset_diff_each(const int32_t (&xw)[W], con
 }
 
 template<int W, class F>
-__device__ __forceinline__ void lpc_offset_diff_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, F &&f)
+__device__ __forceinline__ void lpc_offset_diff_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, long long init, F &&f)
 {
-#define RESIDUAL_CALL(P) lpc_offset_diff_each<P>(xw, q, shift, f)
+#define RESIDUAL_CALL(P) lpc_offset_diff_each<P>(xw, q, shift, init, f)
+	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
+#undef RESIDUAL_CALL
+}
+
+// f(s, pb, P): pb = prediction + b for chunk sample s under an order-P predictor, from a window that holds the samples
+// plus the constant b (xw[t] = x[t] + b, b a small power of two that makes every sample positive): the sum starts from
+// init = (b << shift) - b (sum of the coefficients), so that the taps' share of b is taken out and b itself stays on
+// the shifted result, ((S + b 2^shift) >> shift) = (S >> shift) + b.  Where |prediction| < b the words xw[HIST + s] and
+// pb are both positive and |xw[HIST + s] - pb| on unsigned words (one absolute-difference instruction) is
+// |x - prediction|: no tap for the sample itself.
+template<int P, int W, class F>
+__device__ __forceinline__ void lpc_biased_pred_each(const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, long long init, F &&f)
+{
+#pragma unroll
+	for(int s = 0; s < W - HIST; s++) {
+		long long acc = init;
+#pragma unroll
+		for(int j = 0; j < P; j++) acc += (long long)q[j] * (long long)xw[HIST + s - 1 - j];
+		f(s, __builtin_amdgcn_alignbit((uint32_t)((unsigned long long)acc >> 32), (uint32_t)acc, shift), P);
+	}
+}
+
+template<int W, class F>
+__device__ __forceinline__ void lpc_biased_pred_each_dispatch(uint32_t order, const int32_t (&xw)[W], const int32_t (&q)[HIST], uint32_t shift, long long init, F &&f)
+{
+#define RESIDUAL_CALL(P) lpc_biased_pred_each<P>(xw, q, shift, init, f)
 	RESIDUAL_ORDER_SWITCH(order, RESIDUAL_CALL)
 #undef RESIDUAL_CALL
 }

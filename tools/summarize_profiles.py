@@ -11,9 +11,12 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_round")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 minutes = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+# optional: the directory under gpurun_out/ to read (tools/c3_profile.sh writes prof_c3) and a name part for the outputs
+src = os.path.join(ROOT, "gpurun_out", sys.argv[3] if len(sys.argv) > 3 else "prof_round")
+part = sys.argv[4] if len(sys.argv) > 4 else ""
+tag = tag + ("_" + part if part else "")
 
 
 def short(name):
@@ -46,7 +49,7 @@ with open(os.path.join(ROOT, "profiles", tag + "_pmc_per_kernel.csv"), "w", newl
     for k, cs in sorted(per.items()):
         n = max(len(v) for v in cs.values())
         w.writerow([k, n] + [("%.1f" % (sum(cs[c]) / len(cs[c])) if c in cs else "") for c in counters])
-summary = {"minutes": minutes, "note": "per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; valu_issue_frac = SQ_INSTS_VALU / time / (1024 SIMDs * 2.4 GHz / 2)", "kernels": {}}
+summary = {"minutes": minutes, "workload": open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py, one hour of 16-bit / 44.1 kHz stereo per step", "note": "per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; valu_issue_frac = SQ_INSTS_VALU / time / (1024 SIMDs * 2.4 GHz / 2)", "kernels": {}}
 for k, cs in per.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         fe, wr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
