@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 	uint32_t *chdr = (uint32_t*)(lds_raw + (((size_t)(best_k + parts_cap - lds_raw) + 3u) & ~(size_t)3u));                              // [cg] candidate headers of the current group
 	int32_t *cq = (int32_t*)(chdr + cg_arg);                                       // [cg][HIST] coefficients (orders <= HIST)
 	uint32_t *cinfo = (uint32_t*)(cq + (size_t)cg_arg * HIST);                     // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
-	int32_t *cqsum = (int32_t*)(cinfo + cg_arg);                                   // [cg] sum of the candidate's coefficients (orders <= HIST)
+	long long *cinit = (long long*)(((uintptr_t)(cinfo + cg_arg) + 7u) & ~(uintptr_t)7u);   // [cg] what a linear predictor's 64-bit sums start from
 	// The register windows hold the samples plus this constant where that keeps every sample positive and below 2^31
 	// (lpc_biased_pred_each); fixed predictors of order >= 1 are differences and do not see it
 	const uint32_t bias = (bps <= 26u && !(c.debug & 0x4000u)) ? 0x40000000u : 0u;
@@ -125,8 +125,13 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 		// candidate headers and coefficients of this group: one parallel fetch into LDS
 		for(uint32_t t = tid; t < gn; t += 256) {
 			const size_t rec = fa_cand_idx(c, g, (cb + t));
-			chdr[t] = w.cand_hdr[rec];
-			cqsum[t] = w.cand_q[rec + qrows];   // sum of the coefficients (linear predictors; not read for others)
+			const uint32_t hdr = w.cand_hdr[rec], shift = FA_CAND_SHIFT(hdr);
+			chdr[t] = hdr;
+			// What the multiply-add phase starts a linear predictor's sums from (it reads this before the next barrier): the
+			// constants of lpc_biased_pred_each or lpc_offset_diff_each less the bias's share of every tap, bias times the sum
+			// of the coefficients, which the model stage left behind them
+			const long long qs = (long long)w.cand_q[rec + qrows], b64 = (long long)bias;
+			cinit[t] = (bias && FA_CAND_BOUNDED(hdr)) ? (b64 << shift) - b64 * qs : (long long)(1ull << (31u + shift)) - b64 * (qs - (1ll << shift));
 		}
 		for(uint32_t t = tid; t < gn * HIST; t += 256) {
 			const uint32_t ci = t / HIST, j = t - ci * HIST;
@@ -169,17 +174,17 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 							// biased sample and prediction; else on the offset difference (exact for any values, see
 							// lpc_offset_diff_each), added up in 32 bits for narrow sums - they wrap like the reference's
 							// accumulator - and in 64 bits for wide ones.
-							const long long qs = (long long)cqsum[ci], b64 = (long long)bias;
+							const long long init = cinit[ci];
 							if(bias && FA_CAND_BOUNDED(hdr)) {
 								uint32_t h32 = 0, t32 = 0;
 								auto accum_b = [&](int sidx, uint32_t pb, int P) { if(sidx < P) h32 = sad_u32((uint32_t)xw[HIST + sidx], pb, h32); else t32 = sad_u32((uint32_t)xw[HIST + sidx], pb, t32); };
-								lpc_biased_pred_each_dispatch(order, xw, q, shift, (b64 << shift) - b64 * qs, accum_b);
+								lpc_biased_pred_each_dispatch(order, xw, q, shift, init, accum_b);
 								head = (SUM)h32; tail = (SUM)t32;
 							}
 							else if(sizeof(SUM) == 4 || FA_CAND_BOUNDED(hdr)) {
 								uint32_t h32 = 0, t32 = 0;
 								auto accum_u = [&](int sidx, uint32_t db, int P) { if(sidx < P) h32 = sad_u32(db, 0x80000000u, h32); else t32 = sad_u32(db, 0x80000000u, t32); };
-								lpc_offset_diff_each_dispatch(order, xw, q, shift, (long long)(1ull << (31u + shift)) - b64 * (qs - (1ll << shift)), accum_u);
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, init, accum_u);
 								head = (SUM)h32; tail = (SUM)t32;
 							}
 							else {
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 									const uint32_t m = sad_u32(db, 0x80000000u, 0u);
 									if(sidx < P) h64 += (unsigned long long)m; else t64 += (unsigned long long)m;
 								};
-								lpc_offset_diff_each_dispatch(order, xw, q, shift, (long long)(1ull << (31u + shift)) - b64 * (qs - (1ll << shift)), accum_w);
+								lpc_offset_diff_each_dispatch(order, xw, q, shift, init, accum_w);
 								head = (SUM)h64; tail = (SUM)t64;
 							}
 						}
@@ -426,7 +431,7 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 	b += (size_t)cg * 4u;              // chdr
 	b += (size_t)cg * HIST * 4u;       // cq
 	b += (size_t)cg * 4u;              // cinfo
-	b += (size_t)cg * 4u;              // cqsum
+	b += (size_t)cg * 8u + 8u;         // cinit
 	return (b + 15u) & ~(size_t)15u;
 }
 

@@ -1,7 +1,8 @@
 """GPU tests of the pipelined host path: batches in flight over one or several devices must give the
-stream the reference gives, whatever the batch size, depth and number of devices (two entries naming
-device 0 stand in for two GPUs on a one-GPU box), through the engine-level pipe and through the
-libFLAC-style object."""
+stream the reference gives, whatever the batch size, depth and number of devices, through the engine-level
+pipe and through the libFLAC-style object.  The device lists below say how many entries a pipe gets: on a box
+with several GPUs entry i names GPU i modulo the number present, on a one-GPU box every entry names device 0
+(two entries naming one device stand in for two GPUs)."""
 import numpy as np
 import pytest
 
@@ -11,6 +12,12 @@ from flac_amd import stream, synth
 from test_gpu_stream import _configure, _feed, VC_BLOCK
 
 pytestmark = pytest.mark.gpu
+
+
+def _devices(entries):
+    import torch
+    n = torch.cuda.device_count()
+    return tuple(i % n for i in range(len(entries))) if n > 1 else tuple(entries)
 
 
 def _split(buf, sizes):
@@ -30,7 +37,7 @@ def test_pipe_over_devices_matches_reference_frames(gpu_engine, name, batch, dev
     g = load_golden(name)
     m = g["meta"]
     p = gpu_engine.make_params(m["channels"], m["bps"], m["rate"], **m["params"])
-    pipe = gpu_engine.Pipe(p, batch, devices=devices, depth=depth)
+    pipe = gpu_engine.Pipe(p, batch, devices=_devices(devices), depth=depth)
     pcm = g["pcm"]
     for arr in ((pcm, pcm.astype(np.int16)) if m["bps"] <= 16 else (pcm,)):
         buf, sizes = pipe.encode_host(arr)
@@ -45,7 +52,7 @@ def test_pipe_long_stream_many_batches_matches_oracle(gpu_engine):
     want = ob.oracle_encode(fp, pcm.astype(np.int32))["frames"]
     p = gpu_engine.make_params(2, 16, 44100, level=8)
     for batch, devices, depth in ((7, (0,), 2), (16, (0, 0), 3), (50, (0, 0, 0), 2), (200, (0,), 2)):
-        pipe = gpu_engine.Pipe(p, batch, devices=devices, depth=depth)
+        pipe = gpu_engine.Pipe(p, batch, devices=_devices(devices), depth=depth)
         buf, sizes = pipe.encode_host(pcm)
         assert _split(buf, sizes) == want, (batch, devices, depth)
         buf, sizes = pipe.encode_host(pcm[:4096 * 9])     # the pipe is reusable, here for a run of whole blocks
@@ -62,7 +69,7 @@ def test_stream_object_over_devices_matches_reference(gpu_engine, name, batch, d
     m = g["meta"]
     e = stream.MemoryEncoder(seekable=True)
     _configure(e, m["channels"], m["bps"], m["rate"], m["params"])
-    assert e.set_batch_frames(batch) and e.set_devices(list(devices)) and e.set_batches_in_flight(2)
+    assert e.set_batch_frames(batch) and e.set_devices(list(_devices(devices))) and e.set_batches_in_flight(2)
     assert e.init() == stream.INIT_OK
     bs = e.get_blocksize()
     pcm = g["pcm"]
@@ -89,7 +96,7 @@ def test_stream_object_md5_thread_and_slot_reuse(gpu_engine):
     fp, _ = ob.make_params(2, 16, 44100, level=5)
     want = ob.oracle_encode(fp, pcm)
     e = stream.MemoryEncoder(seekable=True)
-    assert e.set_compression_level(5) and e.set_batch_frames(2) and e.set_devices([0, 0])
+    assert e.set_compression_level(5) and e.set_batch_frames(2) and e.set_devices(list(_devices((0, 0))))
     assert e.init() == stream.INIT_OK
     rng = np.random.default_rng(1)
     i = 0
