@@ -95,13 +95,13 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 	const uint32_t psum_entries = search_psum_entries(cg_arg, parts_cap);
 	uint32_t *lbits = (uint32_t*)(psum + psum_entries);                           // [cg][16]
 	unsigned long long *ckey = (unsigned long long*)(lbits + (size_t)cg_arg * 16u);    // [cg]
-	uint32_t *cpo = (uint32_t*)(ckey + cg_arg);                                    // [cg]
+	long long *cinit = (long long*)(ckey + cg_arg);                                // [cg] what a linear predictor's 64-bit sums start from
+	uint32_t *cpo = (uint32_t*)(cinit + cg_arg);                                   // [cg]
 	uint8_t *kbuf = (uint8_t*)(cpo + cg_arg);                                      // [cg][2*parts_cap] (not kept by the wave pricing)
 	uint8_t *best_k = kbuf + psum_entries;                                         // [parts_cap]
 	uint32_t *chdr = (uint32_t*)(lds_raw + (((size_t)(best_k + parts_cap - lds_raw) + 3u) & ~(size_t)3u));                              // [cg] candidate headers of the current group
 	int32_t *cq = (int32_t*)(chdr + cg_arg);                                       // [cg][HIST] coefficients (orders <= HIST)
 	uint32_t *cinfo = (uint32_t*)(cq + (size_t)cg_arg * HIST);                     // [cg] order | maxpo_c<<8 | minpo_c<<12 | narrow<<16
-	long long *cinit = (long long*)(((uintptr_t)(cinfo + cg_arg) + 7u) & ~(uintptr_t)7u);   // [cg] what a linear predictor's 64-bit sums start from
 	// The register windows hold the samples plus this constant where that keeps every sample positive and below 2^31
 	// (lpc_biased_pred_each); fixed predictors of order >= 1 are differences and do not see it
 	const uint32_t bias = (bps <= 26u && !(c.debug & 0x4000u)) ? 0x40000000u : 0u;
@@ -431,7 +431,7 @@ extern "C" size_t fa_search_lds_bytes(const FaCfg *c, uint32_t cg)
 	b += (size_t)cg * 4u;              // chdr
 	b += (size_t)cg * HIST * 4u;       // cq
 	b += (size_t)cg * 4u;              // cinfo
-	b += (size_t)cg * 8u + 8u;         // cinit
+	b += (size_t)cg * 8u;              // cinit
 	return (b + 15u) & ~(size_t)15u;
 }
 
