@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
 template<bool SPILL>
 __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w)
 {
-	extern __shared__ int32_t xs[];
+	extern __shared__ __align__(16) int32_t xs[];
 	__shared__ uint32_t s_or, s_ne;
 	__shared__ unsigned long long s_err[5];
 
@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 
 	// sums of |k-th difference| over samples [4, n), differences wrapping in 32 bits
 	unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
-	for(uint32_t i = tid + FA_MAX_FIXED_ORDER; i < n; i += 256) {
-		auto X = [&](uint32_t j) -> int32_t { if constexpr(SPILL) return fa_signal(pcm, c, s, base + j); else return xs[j]; };
+	auto X = [&](uint32_t j) -> int32_t { if constexpr(SPILL) return fa_signal(pcm, c, s, base + j); else return xs[j]; };
+	auto one_sample = [&](uint32_t i) {
 		const uint32_t a = (uint32_t)(X(i) >> wasted), b = (uint32_t)(X(i-1) >> wasted), cc = (uint32_t)(X(i-2) >> wasted),
 		               d = (uint32_t)(X(i-3) >> wasted), ee = (uint32_t)(X(i-4) >> wasted);
 		const int32_t d0 = (int32_t)a, d1 = (int32_t)(a - b), d2 = (int32_t)(a - 2u*b + cc),
@@ -71,7 +71,43 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 		e2 += (uint32_t)(d2 < 0 ? 0u - (uint32_t)d2 : (uint32_t)d2);
 		e3 += (uint32_t)(d3 < 0 ? 0u - (uint32_t)d3 : (uint32_t)d3);
 		e4 += (uint32_t)(d4 < 0 ? 0u - (uint32_t)d4 : (uint32_t)d4);
+	};
+	// Samples of at most 25 bits (fourth differences below 2^29, nothing wraps): a thread takes runs of eight consecutive
+	// samples, each difference order from the one below (d_k(i) = d_(k-1)(i) - d_(k-1)(i-1)) and |d_k| added up by the
+	// |a - b| + c instruction on the two order-(k-1) values moved into unsigned order; eight of them fit 32 bits.
+	// Run 0 starts at sample 4; the samples after the last whole run go one by one.
+	const uint32_t bps_max = c.bps + (c.midside ? 1u : 0u);
+	uint32_t done = FA_MAX_FIXED_ORDER;
+	if(!SPILL && bps_max <= 25u && n >= 8u) {
+		const uint32_t runs = n / 8u, B = 0x80000000u;
+		for(uint32_t r = tid; r < runs; r += 256) {
+			const uint32_t i0 = r * 8u;
+			uint32_t v[12];
+			{
+				// three 16-byte LDS reads (the run's start less four samples is a multiple of four words); run 0 has no history
+				const int4 *p4 = (const int4*)(xs + i0);
+				const int4 h = r ? p4[-1] : make_int4(0, 0, 0, 0), lo = p4[0], hi = p4[1];
+				v[0] = (uint32_t)(h.x >> wasted); v[1] = (uint32_t)(h.y >> wasted); v[2] = (uint32_t)(h.z >> wasted); v[3] = (uint32_t)(h.w >> wasted);
+				v[4] = (uint32_t)(lo.x >> wasted); v[5] = (uint32_t)(lo.y >> wasted); v[6] = (uint32_t)(lo.z >> wasted); v[7] = (uint32_t)(lo.w >> wasted);
+				v[8] = (uint32_t)(hi.x >> wasted); v[9] = (uint32_t)(hi.y >> wasted); v[10] = (uint32_t)(hi.z >> wasted); v[11] = (uint32_t)(hi.w >> wasted);
+			}
+			// state before the run's first sample: x, d1, d2, d3 at i0 - 1
+			uint32_t px = v[3], pd1 = v[3] - v[2], pd2 = pd1 - (v[2] - v[1]), pd3 = pd2 - ((v[2] - v[1]) - (v[1] - v[0]));
+			uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+			for(int j = 0; j < 8; j++) {
+				const uint32_t a = v[4 + j], d1 = a - px, d2 = d1 - pd1, d3 = d2 - pd2;
+				if(r != 0u || j >= 4) {
+					a0 = sad_u32(a ^ B, B, a0); a1 = sad_u32(a ^ B, px ^ B, a1); a2 = sad_u32(d1 ^ B, pd1 ^ B, a2);
+					a3 = sad_u32(d2 ^ B, pd2 ^ B, a3); a4 = sad_u32(d3 ^ B, pd3 ^ B, a4);
+				}
+				px = a; pd1 = d1; pd2 = d2; pd3 = d3;
+			}
+			e0 += a0; e1 += a1; e2 += a2; e3 += a3; e4 += a4;
+		}
+		done = runs * 8u;
 	}
+	for(uint32_t i = tid + done; i < n; i += 256) one_sample(i);
 	e0 = wave_sum64(e0); e1 = wave_sum64(e1); e2 = wave_sum64(e2); e3 = wave_sum64(e3); e4 = wave_sum64(e4);
 	if((tid & 63) == 0) {
 		atomicAdd(&s_err[0], e0); atomicAdd(&s_err[1], e1); atomicAdd(&s_err[2], e2); atomicAdd(&s_err[3], e3); atomicAdd(&s_err[4], e4);
