@@ -22,6 +22,7 @@
 // and sums all scale by exact powers of two (nothing overflows below 2^62), so each sum comes
 // out as 4^w times the reference's, bit for bit, and the model stage divides it back out.  Cost: 2*lag + ~8 VALU instructions per sample per lane.
 #include "engine_types.h"
+#include "residual.h"
 
 #define AC_STEP 16
 
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	// signal = (ca * left + cb * right) >> cs: L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), wasted bits left in
 	const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
 	const uint32_t sh = s == 2u ? 1u : 0u;
+	const uint32_t cab = ((uint32_t)ca & 0xffffu) | ((uint32_t)cb << 16);   // the two factors as a pair of 16-bit halves
 
 	auto load16 = [&](uint32_t i0) {
 		RawStereo<PK> r;
@@ -97,10 +99,12 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 			if(i0 + AC_STEP < nloop) nxt = load16(i0 + AC_STEP);
 #pragma unroll
 			for(int j = 0; j < AC_STEP; j++) {
-				int32_t l, r;
-				if(PK == 1) { const uint32_t lr = raw_dword(cur, j); l = (int32_t)(int16_t)(lr & 0xffffu); r = (int32_t)lr >> 16; }
-				else { l = (int32_t)raw_dword(cur, 2 * j); r = (int32_t)raw_dword(cur, 2 * j + 1); }
-				const int32_t x = PK == 1 ? (ca * l + cb * r) >> sh : (int32_t)((uint32_t)ca * (uint32_t)l + (uint32_t)cb * (uint32_t)r) >> sh;   // (32-bit wrapping, like fa_signal)
+				int32_t x;
+				if(PK == 1) x = dot2_i16(raw_dword(cur, j), cab, 0) >> sh;   // ca * left + cb * right straight from the packed word: one instruction
+				else {
+					const int32_t l = (int32_t)raw_dword(cur, 2 * j), r = (int32_t)raw_dword(cur, 2 * j + 1);
+					x = (int32_t)((uint32_t)ca * (uint32_t)l + (uint32_t)cb * (uint32_t)r) >> sh;   // (32-bit wrapping, like fa_signal)
+				}
 				const uint32_t i = i0 + (uint32_t)j;
 				// lpc.c:60; samples past the end of a short block are zero (raw is zero there and the
 				// window index is clamped to stay inside the table)
