@@ -675,11 +675,11 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 				}
 				else if(which == 2u) {
 #pragma unroll
-					for(int j = 0; j < PF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + s.wasted);
+					for(int j = 0; j < PF_W; j++) xw[j] = dot2_i16(raw[j], 0x00010001u, 0) >> (1u + s.wasted);   // left + right by one two-term multiply-add on the halves
 				}
 				else {
 #pragma unroll
-					for(int j = 0; j < PF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> s.wasted;
+					for(int j = 0; j < PF_W; j++) xw[j] = dot2_i16(raw[j], 0xffff0001u, 0) >> s.wasted;            // left - right likewise
 				}
 			}
 			else {

@@ -324,9 +324,13 @@ __global__ void __launch_bounds__(256, 8) fa_prep_stereo16_lean_kernel(const uin
 	uint32_t vo[8];
 #pragma unroll
 	for(int s = 0; s < 4; s++) {
+		// left, right, (left + right) >> 1, left - right from the packed word; the sum and the difference by one two-term
+		// multiply-add on the 16-bit halves
 		auto sig = [&](uint32_t lr) -> uint32_t {
-			const int32_t l = (int32_t)(int16_t)(lr & 0xffffu), r = (int32_t)lr >> 16;
-			return (uint32_t)(s == 0 ? l : s == 1 ? r : s == 2 ? (l + r) >> 1 : l - r);
+			if(s == 0) return (uint32_t)(int32_t)(int16_t)(lr & 0xffffu);
+			if(s == 1) return (uint32_t)((int32_t)lr >> 16);
+			if(s == 2) return (uint32_t)(dot2_i16(lr, 0x00010001u, 0) >> 1);
+			return (uint32_t)dot2_i16(lr, 0xffff0001u, 0);
 		};
 		const uint32_t B = 0x80000000u;
 		uint32_t o = 0, mag = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;

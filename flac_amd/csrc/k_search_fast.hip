@@ -219,11 +219,11 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 				}
 				else if(s == 2u) {
 #pragma unroll
-					for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) + ((int32_t)raw[j] >> 16)) >> (1u + wz);
+					for(int j = 0; j < SF_W; j++) xw[j] = dot2_i16(raw[j], 0x00010001u, 0) >> (1u + wz);   // left + right by one two-term multiply-add on the halves
 				}
 				else {
 #pragma unroll
-					for(int j = 0; j < SF_W; j++) xw[j] = ((int32_t)(int16_t)(raw[j] & 0xffffu) - ((int32_t)raw[j] >> 16)) >> wz;
+					for(int j = 0; j < SF_W; j++) xw[j] = dot2_i16(raw[j], 0xffff0001u, 0) >> wz;            // left - right likewise
 				}
 			};
 			if(wasted == 0u) form(0u); else form(wasted);
