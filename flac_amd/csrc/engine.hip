@@ -305,6 +305,7 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 		o_win = take(G * sizeof(FaWinner)), o_slots = take(F * c.slot_bytes), o_fb = take(F * 4), o_asg = take(F * 4), o_prec = take(F * sizeof(FaPackRec)),
 		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_fshift = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
 		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u),
+		o_short = take(F * 4u),
 		o_lb = take(F * 8u),
 		o_fps = take((p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? G * 320u * 4u : 0u);   // only the 16-bit stereo kernels use it
 	e->arena_bytes = off;
@@ -316,6 +317,7 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 	w.ncand = (uint32_t*)(b + o_ncand); w.cand_hdr = (uint32_t*)(b + o_cand); w.cand_q = (int32_t*)(b + o_cand) + 1;
 	w.winner = (FaWinner*)(b + o_win); w.slots = b + o_slots; w.frame_bytes = (uint32_t*)(b + o_fb); w.assignment = (uint32_t*)(b + o_asg); w.packrec = (FaPackRec*)(b + o_prec);
 	w.xs_spill = (int32_t*)(b + o_spill);
+	w.short_list = (uint32_t*)(b + o_short);
 	w.lb = (unsigned long long*)(b + o_lb); w.out = 0; w.out_cap = 0; w.frame_bytes_out = 0;
 	w.fixed_psum = (p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? (uint32_t*)(b + o_fps) : (uint32_t*)0;
 	w.dbg = (unsigned long long*)(b + o_dbg); w.status = (uint32_t*)(b + o_status); w.offsets = (uint64_t*)(b + o_offs); w.frame_len = (uint32_t*)(b + o_flen); w.frame_num = (uint32_t*)(b + o_fnum); w.frame_shift = (uint32_t*)(b + o_fshift); w.window = (const float*)(b + o_window);
@@ -669,9 +671,10 @@ extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_p
 	if(rc != FLACAMD_OK) return rc;
 	hipStream_t st = (hipStream_t)stream;
 	HIP_TRY(hipSetDevice(e->device));
-	rc = tab_reserve(e, sizeof(uint32_t) * 2u * (size_t)F64, 0);
+	rc = tab_reserve(e, sizeof(uint32_t) * 3u * (size_t)F64, 0);
 	if(rc != FLACAMD_OK) return rc;
 	uint32_t *tab = (uint32_t*)e->h_tab;   // free again: every call ends with the stream synchronised
+	uint32_t nshort = 0;                   // frames shorter than the blocksize (a stream's last), listed for the general search kernel
 	{
 		uint32_t f = 0;
 		for(uint32_t i = 0; i < nstreams; i++) {
@@ -679,17 +682,19 @@ extern "C" int flacamd_encode_streams_device(flacamd_encoder *e, const void *d_p
 			for(uint64_t k = 0; k < nf; k++, f++) {
 				tab[f] = (k + 1 == nf) ? (uint32_t)(h_len[i] - k * N) : N;
 				tab[F64 + f] = (uint32_t)k;
+				if(tab[f] != N) tab[2u * F64 + nshort++] = f;
 			}
 		}
 	}
 	HIP_TRY(hipMemcpyAsync(e->work.frame_len, tab, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(e->work.frame_num, tab + F64, sizeof(uint32_t) * (size_t)F64, hipMemcpyHostToDevice, st));
+	if(nshort) HIP_TRY(hipMemcpyAsync(e->work.short_list, tab + 2u * F64, sizeof(uint32_t) * (size_t)nshort, hipMemcpyHostToDevice, st));
 
 	FaCfg c = e->cfg;
 	c.pcm_format = (uint32_t)pcm_format;
 	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
 	c.last_n = N; c.last_fractional = 0; c.first_frame = 0; c.prev_assignment = 0;
-	c.multi = 1; c.skip_full = 0;
+	c.multi = 1; c.skip_full = 0; c.nshort = nshort;
 	return run_batch(e, c, d_pcm, d_out, out_cap, d_frame_bytes, h_total_bytes, st);
 }
 
@@ -763,14 +768,15 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_md5, hipEventDisableTiming));
 	}
-	// host staging: frame_len[F] frame_num[F] frame_shift[F] | starts[n] ends[n] (u64) first[n] nframes[n] (u32) | stream_off[n + 1] (coming back)
+	// host staging: frame_len[F] frame_num[F] frame_shift[F] short frames[F] | starts[n] ends[n] (u64) first[n] nframes[n] (u32) | stream_off[n + 1] (coming back)
 	const size_t F = (size_t)F64, n = nclips;
-	const size_t o_clip = (3u * F * 4u + 7u) & ~(size_t)7u, clip_bytes = n * (8u + 8u + 4u + 4u), o_back = o_clip + ((clip_bytes + 7u) & ~(size_t)7u);
+	const size_t o_clip = (4u * F * 4u + 7u) & ~(size_t)7u, clip_bytes = n * (8u + 8u + 4u + 4u), o_back = o_clip + ((clip_bytes + 7u) & ~(size_t)7u);
 	const size_t d_dig_off = (clip_bytes + 15u) & ~(size_t)15u, d_soff = d_dig_off + n * 16u;
 	rc = tab_reserve(e, o_back + (n + 1u) * 8u, d_soff + (n + 1u) * 8u);
 	if(rc != FLACAMD_OK) return rc;
 	uint8_t *hb = (uint8_t*)e->h_tab;
-	uint32_t *flen = (uint32_t*)hb, *fnum = flen + F, *fshift = fnum + F;
+	uint32_t *flen = (uint32_t*)hb, *fnum = flen + F, *fshift = fnum + F, *fshort = fshift + F;
+	uint32_t nshort = 0;   // frames shorter than the blocksize (a clip's last), listed for the general search kernel
 	uint64_t *cs = (uint64_t*)(hb + o_clip), *ce = cs + n; uint32_t *cf = (uint32_t*)(ce + n), *cn = cf + n;
 	{
 		uint32_t f = 0;
@@ -781,6 +787,7 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 				flen[f] = (k + 1 == nf) ? (uint32_t)(h_len[i] - k * N) : N;
 				fnum[f] = (uint32_t)k;
 				fshift[f] = (uint32_t)FLACAMD_STREAM_HEAD_BYTES * (i + 1u);
+				if(flen[f] != N) fshort[nshort++] = f;
 			}
 		}
 	}
@@ -790,6 +797,7 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 	HIP_TRY(hipMemcpyAsync(e->work.frame_len, flen, F * 4u, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(e->work.frame_num, fnum, F * 4u, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(e->work.frame_shift, fshift, F * 4u, hipMemcpyHostToDevice, st));
+	if(nshort) HIP_TRY(hipMemcpyAsync(e->work.short_list, fshort, (size_t)nshort * 4u, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(db, hb + o_clip, clip_bytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipEventRecord(e->ev_tab, st));
 	// the digests: one lane per clip, a serial chain as long as the clip (md5.c:394-420); beside the coding stages -
@@ -806,7 +814,7 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 	c.pcm_format = (uint32_t)pcm_format;
 	c.F = (uint32_t)F64; c.G = c.F * c.nsig;
 	c.last_n = N; c.last_fractional = 0; c.first_frame = 0; c.prev_assignment = 0;
-	c.multi = 2; c.skip_full = 0;
+	c.multi = 2; c.skip_full = 0; c.nshort = nshort;
 	uint64_t total = 0;
 	rc = run_batch(e, c, d_pcm, d_out, out_cap, 0, &total, st);
 	const uint64_t need = total + (uint64_t)FLACAMD_STREAM_HEAD_BYTES * nclips;

@@ -30,7 +30,9 @@ struct FaCfg {
 	uint32_t last_n;          // samples in the last frame of the batch
 	uint32_t last_fractional; // last frame is the short final block of the stream
 	uint32_t multi;           // the batch holds several complete streams: frame lengths and numbers come from FaWork::frame_len / frame_num; 2 = each stream's frames are also moved FaWork::frame_shift bytes further in the output (room for the stream heads)
-	uint32_t skip_full;       // general search kernel: full-length frames are left to the register-resident kernel
+	uint32_t skip_full;       // general search kernel: full-length frames are left to the register-resident kernel; its workgroups then cover
+	                          // only the nshort frames listed in FaWork::short_list (the short final blocks of a batch of several streams)
+	uint32_t nshort;
 	uint32_t spill;           // blocks above FA_LDS_BLOCKSIZE samples: the general kernels keep their copy of the signal in FaWork::xs_spill instead of LDS
 	uint32_t first_frame;     // frame number of frame 0 of the batch
 	uint32_t prev_assignment;
@@ -130,6 +132,7 @@ struct FaWork {
 	uint32_t *frame_num;   // [F] frame number within its stream, multi-stream batches only
 	uint32_t *frame_shift; // [F] bytes added to the frame's output offset (FaCfg::multi == 2)
 	int32_t  *xs_spill;    // [G][xs_words_for(N)] signal copies of the general kernels when FaCfg::spill (else unused)
+	uint32_t *short_list;  // [nshort] frames of a batch of several streams that are shorter than the blocksize (FaCfg::skip_full)
 	const float *window;   // [num_apod][N]
 	const uint16_t *crc16_table4; // [4][256] CRC-16 of one byte followed by 0..3 zero bytes (crc.c:77-110 polynomial)
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial

@@ -61,9 +61,11 @@ __global__ void __launch_bounds__(256, 4) fa_search_kernel(const void *__restric
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	__shared__ SearchShared sh;
 
-	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig) + g0, f = g / c.nsig, s = g - f * c.nsig;   // g0: first signal of the range this launch covers; the signals of a frame share an XCD
+	// g0: first signal of the range this launch covers; the signals of a frame share an XCD.  With skip_full the launch covers
+	// the listed short frames only (the others are coded by the register-resident kernel)
+	const uint32_t gb = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig);
+	const uint32_t g = c.skip_full ? w.short_list[gb / c.nsig] * c.nsig + gb % c.nsig : gb + g0, f = g / c.nsig, s = g - f * c.nsig;
 	const uint32_t n = fa_frame_len(c, w, f);
-	if(c.skip_full && n == c.N) return;   // coded by the register-resident kernel
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t wasted = w.wasted[g];
@@ -459,7 +461,7 @@ extern "C" void fa_launch_search2(const void *pcm, const FaCfg *c, const FaWork 
 	fa_launch_search_fast(pcm, c, w, cg, sum64, fast_frames, st);
 	// several streams in one batch: short final blocks sit anywhere, both kernels cover all frames and each skips the other's
 	cc.skip_full = (c->multi && fast_frames) ? 1u : 0u;
-	const uint32_t g0 = c->multi ? 0u : fast_frames * c->nsig, rest = c->G - g0;
+	const uint32_t g0 = c->multi ? 0u : fast_frames * c->nsig, rest = cc.skip_full ? c->nshort * c->nsig : c->G - g0;
 	if(rest == 0) return;
 	c = &cc;
 	const size_t lds = fa_search_lds_bytes(c, cg);

@@ -5,7 +5,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/pmc_quick"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -o p -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-decode --no-configs --no-api --steps 2 --warmup 1 > "$OUT/sq.log" 2>&1 || { echo "pmc pass failed"; tail -5 "$OUT/sq.log"; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/sq" -o p -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-decode --no-configs --no-api --no-sharded --steps 2 --warmup 1 > "$OUT/sq.log" 2>&1 || { echo "pmc pass failed"; tail -5 "$OUT/sq.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 per = collections.defaultdict(lambda: collections.defaultdict(list))
