@@ -143,7 +143,8 @@ __global__ void __launch_bounds__(256) fa_prep_stereo16_kernel(const uint32_t *_
 {
 	__shared__ PrepFastShared sh;
 	__shared__ uint32_t s_fps[4][5][64];   // per signal and difference order: sums over the finest partitions (FaCfg::fixed_psum)
-	const uint32_t f = frame0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	// only_short = 2: the workgroups cover the short frames listed in FaWork::short_list (a batch of several streams)
+	const uint32_t f = only_short == 2u ? w.short_list[blockIdx.x] : frame0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t n = fa_frame_len(c, w, f);
 	if(only_short && n == c.N) return;     // full-length frames went to the kernel below
 	if(only_short) __builtin_amdgcn_s_setprio(3);   // a few workgroups beside tens of thousands of the other kernel's: do not queue behind them for every instruction
@@ -429,7 +430,7 @@ extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w,
 		if(fa_prep_lean_ok(c)) {
 			hipLaunchKernelGGL(fa_prep_stereo16_lean_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w);
 			// short blocks: anywhere in a batch of several streams, else the last frame at most
-			if(c->multi) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st_short, (const uint32_t*)pcm, *c, *w, 0u, 1u);
+			if(c->multi) { if(c->nshort) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->nshort), dim3(256), 0, st_short, (const uint32_t*)pcm, *c, *w, 0u, 2u); }
 			else if(c->last_n != c->N) hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(1), dim3(256), 0, st_short, (const uint32_t*)pcm, *c, *w, c->F - 1u, 1u);
 			return;
 		}
