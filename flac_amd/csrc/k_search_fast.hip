@@ -24,6 +24,7 @@
 #include "engine_types.h"
 #include "residual.h"
 #include "wave_ops.h"
+#include <type_traits>
 
 #define SF_THREADS 256
 #define SF_CH 16
@@ -312,39 +313,50 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 			uint32_t nfixed = 0;
 			while(nfixed < gn && FA_CAND_KIND(chdr[nfixed]) == 0) nfixed++;
 			if(nfixed && !take_fps) {
-				SUM fT[5], fH[5];
+				// Per-thread sums in 32 bits where sixteen magnitudes cannot carry out of them: always for 32-bit partition sums,
+				// and for samples of at most 25 bits (a fourth difference stays below 2^28); then |a - b| + c in one instruction
+				auto fixed_pass = [&](auto zero, auto always_sad) __attribute__((always_inline)) {
+					typedef decltype(zero) ACC;
+					const bool use_sad = decltype(always_sad)::value || sad_on;
+					ACC fT[5], fH[5];
 #pragma unroll
-				for(int k = 0; k < 5; k++) { fT[k] = 0; fH[k] = 0; }
-				const uint32_t B = 0x80000000u;
-				auto add_abs = [&](SUM &acc, uint32_t a, uint32_t b) {
-					if(sad_on) acc = (SUM)sad_u32(a ^ B, b ^ B, (uint32_t)acc);
-					else acc += abs_u32((int32_t)(a - b));
+					for(int k = 0; k < 5; k++) { fT[k] = 0; fH[k] = 0; }
+					const uint32_t B = 0x80000000u;
+					auto add_abs = [&](ACC &acc, uint32_t a, uint32_t b) {
+						if(sizeof(ACC) == 4 && use_sad) acc = (ACC)sad_u32(a ^ B, b ^ B, (uint32_t)acc);
+						else acc += abs_u32((int32_t)(a - b));
+					};
+					uint32_t px = (uint32_t)xw[HIST - 1], pd1, pd2, pd3;
+					{
+						const uint32_t x2 = (uint32_t)xw[HIST - 2], x3 = (uint32_t)xw[HIST - 3], x4 = (uint32_t)xw[HIST - 4];
+						const uint32_t e1 = x2 - x3, e2 = x3 - x4;      // d1(-2), d1(-3)
+						pd1 = px - x2;
+						const uint32_t g2 = e1 - e2;                      // d2(-2)
+						pd2 = pd1 - e1;
+						pd3 = pd2 - g2;
+					}
+#pragma unroll
+					for(int j = 0; j < SF_CH; j++) {
+						const uint32_t a = (uint32_t)xw[HIST + j];
+						const uint32_t d1 = a - px, d2 = d1 - pd1, d3 = d2 - pd2;
+						add_abs(fT[0], a, 0u);
+						add_abs(j < 1 ? fH[1] : fT[1], a, px);
+						add_abs(j < 2 ? fH[2] : fT[2], d1, pd1);
+						add_abs(j < 3 ? fH[3] : fT[3], d2, pd2);
+						add_abs(j < 4 ? fH[4] : fT[4], d3, pd3);
+						px = a; pd1 = d1; pd2 = d2; pd3 = d3;
+					}
+					for(uint32_t ci = 0; ci < nfixed; ci++) {
+						const uint32_t order = FA_CAND_ORDER(chdr[ci]);
+						SUM vT = (SUM)fT[4], vH = (SUM)fH[4];
+						if(order == 0u) { vT = (SUM)fT[0]; vH = 0; } else if(order == 1u) { vT = (SUM)fT[1]; vH = (SUM)fH[1]; } else if(order == 2u) { vT = (SUM)fT[2]; vH = (SUM)fH[2]; } else if(order == 3u) { vT = (SUM)fT[3]; vH = (SUM)fH[3]; }
+						if(active) atomicAdd(&psum[(size_t)ci * SF_ROW + part], vT + (tid >= 1u ? vH : (SUM)0));
+					}
 				};
-				uint32_t px = (uint32_t)xw[HIST - 1], pd1, pd2, pd3;
-				{
-					const uint32_t x2 = (uint32_t)xw[HIST - 2], x3 = (uint32_t)xw[HIST - 3], x4 = (uint32_t)xw[HIST - 4];
-					const uint32_t e1 = x2 - x3, e2 = x3 - x4;      // d1(-2), d1(-3)
-					pd1 = px - x2;
-					const uint32_t g2 = e1 - e2;                      // d2(-2)
-					pd2 = pd1 - e1;
-					pd3 = pd2 - g2;
-				}
-#pragma unroll
-				for(int j = 0; j < SF_CH; j++) {
-					const uint32_t a = (uint32_t)xw[HIST + j];
-					const uint32_t d1 = a - px, d2 = d1 - pd1, d3 = d2 - pd2;
-					add_abs(fT[0], a, 0u);
-					add_abs(j < 1 ? fH[1] : fT[1], a, px);
-					add_abs(j < 2 ? fH[2] : fT[2], d1, pd1);
-					add_abs(j < 3 ? fH[3] : fT[3], d2, pd2);
-					add_abs(j < 4 ? fH[4] : fT[4], d3, pd3);
-					px = a; pd1 = d1; pd2 = d2; pd3 = d3;
-				}
-				for(uint32_t ci = 0; ci < nfixed; ci++) {
-					const uint32_t order = FA_CAND_ORDER(chdr[ci]);
-					SUM vT = fT[4], vH = fH[4];
-					if(order == 0u) { vT = fT[0]; vH = 0; } else if(order == 1u) { vT = fT[1]; vH = fH[1]; } else if(order == 2u) { vT = fT[2]; vH = fH[2]; } else if(order == 3u) { vT = fT[3]; vH = fH[3]; }
-					if(active) atomicAdd(&psum[(size_t)ci * SF_ROW + part], vT + (tid >= 1u ? vH : (SUM)0));
+				if constexpr(sizeof(SUM) == 4) fixed_pass((uint32_t)0, std::false_type{});
+				else {
+					if(bps <= 25u && !(dbg & 0x4000u)) fixed_pass((uint32_t)0, std::true_type{});
+					else fixed_pass((SUM)0, std::false_type{});
 				}
 			}
 			if(use_dot2) {
