@@ -51,7 +51,9 @@ def encode_groups_device(plans, device):
     digests = [None] * len(plans)
     if len(plans) > 1:
         # the digests of all groups in one pass beside the coding stages: as long as the longest clip, once
-        md5_stream = torch.cuda.Stream(device=device)
+        # (a stream of another priority: streams of one priority share the process's few hardware queues in turn, and a
+        # group whose stream landed in the queue of this pass would wait behind it for as long as the longest clip)
+        md5_stream = torch.cuda.Stream(device=device, priority=-1)
         digests = [torch.empty(len(p[3]) * 16, dtype=torch.uint8, device=p[1].device) for p in plans]
         engine.md5_groups_device(device, [(p[1].data_ptr(), p[2], p[0].channels, int(p[0].params.bits_per_sample), p[3], p[4], d.data_ptr())
                                           for p, d in zip(plans, digests)], stream=md5_stream.cuda_stream)

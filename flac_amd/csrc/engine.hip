@@ -306,7 +306,7 @@ static int encoder_create_once(flacamd_encoder **out, int device, const flacamd_
 		o_status = take(256), o_offs = take((F + 1) * 8), o_flen = take(F * 4), o_fnum = take(F * 4), o_fshift = take(F * 4), o_window = take((size_t)c.num_apod * c.N * 4), o_crc = take(2u * (1024u + (size_t)c.slot_bytes + FA_PACK_LARGE_WORDS + 1024u)), o_dbg = take((size_t)FA_DBG_WORDS * 8u),
 		o_spill = take(c.spill ? G * (size_t)xs_words_for(c.N) * 4u : 0u),
 		o_short = take(F * 4u),
-		o_lb = take(F * 8u),
+		o_lb = take(F * 12u),   // look-back states (u64) and the flags of late frames (u32) of the pack kernel that writes in place
 		o_fps = take((p.channels == 2 && p.bits_per_sample <= 16 && p.blocksize <= 4096 && (p.blocksize % 16u) == 0) ? G * 320u * 4u : 0u);   // only the 16-bit stereo kernels use it
 	e->arena_bytes = off;
 	hipError_t he = hipMalloc(&e->arena, e->arena_bytes);
@@ -596,7 +596,7 @@ static int enqueue_batch(flacamd_encoder *e, const FaCfg &c_in, const void *d_pc
 	c.direct_out = (fa_pack_direct_ok(d_pcm, &c) && !(c.debug & 3u)) ? 1u : 0u;
 	FaWork ww = e->work;
 	ww.out = (uint8_t*)d_out; ww.out_cap = out_cap; ww.frame_bytes_out = d_frame_bytes;
-	if(c.direct_out) HIP_TRY(hipMemsetAsync(ww.lb, 0, (size_t)c.F * 8u, st));
+	if(c.direct_out) HIP_TRY(hipMemsetAsync(ww.lb, 0, (size_t)c.F * 12u, st));
 	if(!(c.debug & 3u)) fa_launch_pack(d_pcm, &c, &ww, st);
 	if(tm) hipEventRecord(e->cur_ev[5], st);
 	if(c.direct_out) fa_launch_offsets(&c, &ww, st);

@@ -138,7 +138,8 @@ struct FaWork {
 	const uint16_t *crc16_xpw;    // [bitbuf words + 1] x^(32 w) mod the CRC-16 polynomial
 	unsigned long long *dbg;      // [FA_DBG_WORDS] development timestamps (FLACAMD_DEBUG & 0x1000), unused in production
 	// FaCfg::direct_out (set per call)
-	unsigned long long *lb;       // [F] look-back state of every frame, zeroed before the pack kernel: bits 63..62 = 0 nothing yet, 1 the frame's own size, 2 the size of all frames up to and including it; the rest the value
+	unsigned long long *lb;       // [F] look-back state of every frame, zeroed before the pack kernel: bits 63..62 = 0 nothing yet, 1 the frame's own size, 2 the size of all frames up to and including it; the rest the value.
+	                              // Behind them u32 [F]: nonzero for a frame that went to its slot because its place was not known in time (fa_place_late_kernel)
 	uint8_t  *out;                // the caller's output buffer
 	unsigned long long out_cap;   // its size
 	uint32_t *frame_bytes_out;    // the caller's array of frame sizes (may be null)

@@ -122,30 +122,103 @@ __device__ __forceinline__ void md5_three_blocks(uint32_t (&h)[4], const Md5Chun
 	}
 }
 
-// one stream: [s0, s1) of pcm in wide samples -> 16 bytes at digest
-__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest);
+// one stream: [s0, s1) of pcm in wide samples -> 16 bytes at digest.  Every lane of a workgroup's first wave calls it (a
+// lane without a stream with valid = false and an empty range); the second wave runs md5_fetcher beside it.
+struct Md5Shared;
+__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest, bool valid, Md5Shared &sh);
 
-__global__ void __launch_bounds__(64) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
+// The bulk of a workgroup's 64 streams comes in through its second wave, 256 bytes of memory per stream and round: sixteen
+// lanes take the sixteen 16-byte pieces of one stream's next 256 bytes, so a load instruction touches four streams (four
+// pages, eight or twelve cache lines) instead of sixty-four, and the pieces go through LDS rows - two sets, filled and
+// read in turn, one barrier per round - to the lane of the first wave that hashes the stream.  (With every hashing lane
+// fetching its own stream 16 bytes at a time the kernel asked for an address translation per lane and load, and the coding
+// kernels running beside it took three to five times as long as alone; with the hashing lanes doing the shared fetch
+// themselves the hash chain, which is all that bounds this kernel, grew by a quarter.)
+#define MD5_ROW 17   // uint4 per LDS row: 256 bytes + 16 of padding (rows a power of two apart would share banks)
+struct Md5Shared {
+	uint4 stage[2][64][MD5_ROW];
+	unsigned long long ptr[64];   // where each stream's bulk starts
+	uint32_t rounds[64];          // ... and how many rounds of 256 bytes it has
+	uint32_t mode, maxr;          // 0: no shared fetch; 4: two-byte samples held as int16 (four blocks a round); 3: three-byte samples held as int32 (three)
+};
+
+__device__ __forceinline__ void md5_fetcher(Md5Shared &sh)
+{
+	const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, piece = lane & 15u;
+	__syncthreads();
+	const uint32_t maxr = sh.maxr;
+	if(!sh.mode) return;
+	// where this lane fetches for the sixteen streams it serves (streams 4 i + sub) and how many rounds each has left
+	const uint8_t *pp[16];
+	uint32_t cnt[16];
+#pragma unroll
+	for(int i = 0; i < 16; i++) { pp[i] = (const uint8_t*)(uintptr_t)sh.ptr[4 * i + (int)sub] + piece * 16u; cnt[i] = sh.rounds[4 * i + (int)sub]; }
+	uint4 pre[16];
+	auto fetch_round = [&]() {
+#pragma unroll
+		for(int i = 0; i < 16; i++) {
+			pre[i] = cnt[i] ? md5_load16(pp[i]) : make_uint4(0u, 0u, 0u, 0u);
+			if(cnt[i]) { pp[i] += 256; cnt[i]--; }
+		}
+	};
+	fetch_round();
+	for(uint32_t r = 0; r < maxr; r++) {
+#pragma unroll
+		for(int i = 0; i < 16; i++) sh.stage[r & 1u][4 * i + (int)sub][piece] = pre[i];
+		fetch_round();      // the next round's loads are in flight while the first wave hashes this one
+		__syncthreads();
+	}
+}
+
+// the first wave's side: BLOCKS as Md5Shared::mode; `rounds` of this lane's stream, maxr the most of any lane
+template<int BLOCKS>
+__device__ __forceinline__ void md5_bulk_hash(uint32_t (&h)[4], uint32_t rounds, uint32_t maxr, Md5Shared &sh)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	for(uint32_t r = 0; r < maxr; r++) {
+		__syncthreads();
+		if(r < rounds) {
+			Md5Chunk<16> cur;
+#pragma unroll
+			for(int j = 0; j < 16; j++) cur.v[j] = sh.stage[r & 1u][lane][j];
+			if(BLOCKS == 4) {
+				Md5Chunk<8> a, b;
+#pragma unroll
+				for(int j = 0; j < 8; j++) { a.v[j] = cur.v[j]; b.v[j] = cur.v[8 + j]; }
+				md5_two_blocks(h, a); md5_two_blocks(h, b);
+			}
+			else md5_three_blocks(h, cur);
+		}
+	}
+}
+
+__global__ void __launch_bounds__(128) fa_md5_kernel(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps,
 	const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends, uint32_t nstreams, uint8_t *__restrict__ digests)
 {
+	__shared__ Md5Shared sh;
+	if(threadIdx.x >= 64u) { md5_fetcher(sh); return; }
 	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
-	if(sidx >= nstreams) return;
-	md5_one_stream(pcm, fmt, channels, bps, starts[sidx], ends[sidx], digests + (size_t)sidx * 16u);
+	const bool valid = sidx < nstreams;
+	md5_one_stream(pcm, fmt, channels, bps, valid ? starts[sidx] : 0ull, valid ? ends[sidx] : 0ull, digests + (size_t)(valid ? sidx : 0u) * 16u, valid, sh);
 }
 
 // the same for streams of several buffers and formats: what a lane hashes comes from its own record (a group's lanes
 // are next to one another, so a wave is nearly always of one format)
 struct FaMd5Rec { const void *pcm; uint8_t *digest; uint64_t s0, s1; uint32_t fmt, channels, bps, pad; };
-__global__ void __launch_bounds__(64) fa_md5_multi_kernel(const FaMd5Rec *__restrict__ recs, uint32_t nstreams)
+__global__ void __launch_bounds__(128) fa_md5_multi_kernel(const FaMd5Rec *__restrict__ recs, uint32_t nstreams)
 {
+	__shared__ Md5Shared sh;
+	if(threadIdx.x >= 64u) { md5_fetcher(sh); return; }
 	const uint32_t sidx = blockIdx.x * 64u + threadIdx.x;
-	if(sidx >= nstreams) return;
-	const FaMd5Rec r = recs[sidx];
-	if(!r.pcm) return;   // filler up to a whole wave
-	md5_one_stream(r.pcm, r.fmt, r.channels, r.bps, r.s0, r.s1, r.digest);
+	FaMd5Rec r;
+	r.pcm = 0; r.digest = 0; r.s0 = 0; r.s1 = 0; r.fmt = FLACAMD_PCM_S16; r.channels = 1; r.bps = 16; r.pad = 0;
+	if(sidx < nstreams) r = recs[sidx];
+	const bool valid = r.pcm != 0;   // (else filler up to a whole wave)
+	if(!valid) { r.s0 = 0; r.s1 = 0; }
+	md5_one_stream(r.pcm, r.fmt, r.channels, r.bps, r.s0, r.s1, r.digest, valid, sh);
 }
 
-__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest)
+__device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uint32_t fmt, uint32_t channels, uint32_t bps, uint64_t s0, uint64_t s1, uint8_t *__restrict__ digest, bool valid, Md5Shared &sh)
 {
 	const uint32_t nb = (bps + 7u) / 8u;
 	uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
@@ -153,6 +226,25 @@ __device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uin
 	uint64_t t = s0 * channels;
 	const uint64_t tend = s1 * channels;
 	uint64_t total = 0;
+	// ... through the second wave where the streams are all of one of the two common layouts (lanes without a stream go along)
+	{
+		const bool is16 = nb == 2u && fmt == FLACAMD_PCM_S16, is24 = nb == 3u && fmt == FLACAMD_PCM_S32;
+		const uint32_t mode = __all((is16 || !valid) ? 1 : 0) ? 4u : __all((is24 || !valid) ? 1 : 0) ? 3u : 0u;
+		const uint32_t per = mode == 4u ? 128u : 64u;   // values per round of 256 bytes
+		const uint64_t nr = (mode && valid) ? (tend - t) / per : 0ull;
+		const uint32_t rounds = nr < 0xffffffffull ? (uint32_t)nr : 0xffffffffu;
+		uint32_t maxr = rounds;
+#pragma unroll
+		for(int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)maxr, o, 64); maxr = v > maxr ? v : maxr; }
+		const uint32_t lane = threadIdx.x & 63u;
+		sh.ptr[lane] = (unsigned long long)(uintptr_t)((const uint8_t*)pcm + t * (mode == 4u ? 2u : 4u));
+		sh.rounds[lane] = rounds;
+		if(lane == 0u) { sh.mode = maxr ? mode : 0u; sh.maxr = maxr; }
+		__syncthreads();
+		if(mode == 4u && maxr) md5_bulk_hash<4>(h, rounds, maxr, sh);
+		else if(mode == 3u && maxr) md5_bulk_hash<3>(h, rounds, maxr, sh);
+		t += (uint64_t)rounds * per; total += (uint64_t)rounds * (mode == 4u ? 256u : 192u);
+	}
 	if(nb == 2u && fmt == FLACAMD_PCM_S16 && t + 64u <= tend) {
 		const uint8_t *p = (const uint8_t*)pcm + t * 2u;
 		Md5Chunk<8> nxt = md5_fetch<8>(p);
@@ -207,7 +299,7 @@ __device__ __forceinline__ void md5_one_stream(const void *__restrict__ pcm, uin
 	push(0x80u);
 	while(fill != 56u) push(0u);
 	for(uint32_t k = 0; k < 8; k++) push((uint32_t)(bits >> (8u * k)) & 0xffu);
-	for(uint32_t i = 0; i < 16; i++) digest[i] = (uint8_t)(h[i >> 2] >> (8u * (i & 3u)));
+	if(valid) for(uint32_t i = 0; i < 16; i++) digest[i] = (uint8_t)(h[i >> 2] >> (8u * (i & 3u)));
 }
 
 extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format, uint32_t channels, uint32_t bits_per_sample,
@@ -226,7 +318,7 @@ extern "C" int flacamd_md5_device(int device, const void *d_pcm, int pcm_format,
 	int rc = FLACAMD_OK;
 	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	if(rc == FLACAMD_OK) {
-		hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
+		hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(128), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
 		if(hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 		if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	}
@@ -285,7 +377,7 @@ extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_
 	// nothing in the array has to start at zero: the kernel reads offsets[0..nstreams] and writes every byte of
 	// digests[0..nstreams), both overwritten here, and nothing beyond them is copied out
 	if(hipMemcpyAsync(d_off, h_offsets, (size_t)(nstreams + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
-	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
+	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(128), 0, st, d_pcm, (uint32_t)pcm_format, channels, bits_per_sample, d_off, d_off + 1, nstreams, d_dig);
 	int rc = hipGetLastError() == hipSuccess ? FLACAMD_OK : FLACAMD_E_DEVICE;
 	if(rc == FLACAMD_OK && hipMemcpyAsync(h_digests, d_dig, (size_t)nstreams * 16, hipMemcpyDeviceToHost, st) != hipSuccess) rc = FLACAMD_E_DEVICE;
 	if(hipStreamSynchronize(st) != hipSuccess) rc = FLACAMD_E_DEVICE;
@@ -296,7 +388,7 @@ extern "C" int flacamd_md5_device_static(int device, const void *d_pcm, int pcm_
 extern "C" void fa_launch_md5(const void *d_pcm, uint32_t pcm_format, uint32_t channels, uint32_t bits_per_sample, const uint64_t *d_starts, const uint64_t *d_ends,
 	uint32_t nstreams, uint8_t *d_digests, hipStream_t st)
 {
-	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(64), 0, st, d_pcm, pcm_format, channels, bits_per_sample, d_starts, d_ends, nstreams, d_digests);
+	hipLaunchKernelGGL(fa_md5_kernel, dim3((nstreams + 63u) / 64u), dim3(128), 0, st, d_pcm, pcm_format, channels, bits_per_sample, d_starts, d_ends, nstreams, d_digests);
 }
 
 // ---- the digests of several clip batches in one launch
@@ -350,7 +442,7 @@ extern "C" int flacamd_md5_groups_device(int device, uint32_t ngroups, const fla
 	}
 	hipStream_t st = (hipStream_t)stream;
 	if(hipMemcpyAsync(b.d, b.h, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return FLACAMD_E_DEVICE;
-	hipLaunchKernelGGL(fa_md5_multi_kernel, dim3((uint32_t)(total / 64u)), dim3(64), 0, st, (const FaMd5Rec*)b.d, (uint32_t)total);
+	hipLaunchKernelGGL(fa_md5_multi_kernel, dim3((uint32_t)(total / 64u)), dim3(128), 0, st, (const FaMd5Rec*)b.d, (uint32_t)total);
 	if(hipGetLastError() != hipSuccess) return FLACAMD_E_DEVICE;
 	if(hipEventRecord(b.done, st) == hipSuccess) b.pending = true;
 	else if(hipStreamSynchronize(st) != hipSuccess) return FLACAMD_E_DEVICE;

@@ -460,6 +460,7 @@ __global__ void __launch_bounds__(256, 3) fa_pack_kernel(const void *__restrict_
 #define PF_LB_MASK (3ull << 62)
 #define PF_CH 16
 #define PF_W (HIST + PF_CH)
+#define PF_LB_SPINS 64u   // polls of a silent predecessor before a frame goes to its slot instead of its place (see the look-back)
 
 struct PackFastShared {
 	uint32_t wave_tot[PF_THREADS / 64][2];
@@ -880,7 +881,7 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 	// sum of the sizes of the frames before it.  Every workgroup has published its own size (state "own"); the first wave
 	// walks back over its predecessors 64 at a time, adding sizes, until it meets one that already knows the total up to and
 	// including itself (state "all"), then publishes its own total.  Workgroups are handed out in index order, so a
-	// predecessor that has not published yet is running (or done) and will: the wait is short and cannot deadlock.
+	// predecessor that has not published yet is normally running (or done) and will publish soon; the wait is bounded.
 	const uint32_t full = total_bits >> 5;
 	if(c.direct_out && tid < 64u) {
 		unsigned long long before = 0;
@@ -896,9 +897,11 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 				const uint32_t stop = knows_all ? (uint32_t)__builtin_ctzll(knows_all) : 64u;   // nearest predecessor that knows its total
 				const unsigned long long upto = stop >= 63u ? ~0ull : ((2ull << stop) - 1ull);
 				if(silent & upto) {
-					// a bound on the wait, so that this wave ends whatever happens to the others: the batch then counts as one with
-					// a frame that did not fit, and goes through the slot-and-copy path once more
-					if(++waits > (1u << 22)) { gave_up = true; break; }
+					// A short bound on the wait: the frame then goes to its slot and fa_place_late_kernel moves it afterwards.  When
+					// this kernel shares the chip with others (another encoder's pack kernel, another process), an XCD may be so full
+					// of other work that it launches its share of the workgroups late: frames on the other XCDs would spin for them
+					// while holding the very CU slots the others are waiting for.  Nothing here waits for long.
+					if(++waits > PF_LB_SPINS) { gave_up = true; break; }
 					__builtin_amdgcn_s_sleep(2);
 					continue;
 				}
@@ -910,8 +913,8 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 				hi -= 64;
 			}
 			if(tid == 0 && !gave_up) __hip_atomic_store(&w.lb[f], PF_LB_ALL | (before + frame_nb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if(tid == 0 && gave_up) atomicOr(w.status, 1u);
 		}
+		if((c.debug & 0x20000000u) && f % 3u == 1u) gave_up = true;   // development switch: every third frame takes the late path
 		if(tid == 0) sh.out_off = gave_up ? ~0ull : before + (c.multi == 2u ? w.frame_shift[f] : 0u);
 	}
 
@@ -933,13 +936,18 @@ __global__ void __launch_bounds__(PF_THREADS, PACKED16 ? (NARROW ? 6 : 5) : 4) f
 	const uint32_t tail_bits = total_bits & 31u, tail_bytes = (tail_bits + 7u) >> 3;
 	const uint32_t body_bytes = full * 4u + tail_bytes, nb = body_bytes + 2u;
 	const unsigned long long off = c.direct_out ? sh.out_off : 0ull;
-	const bool place = c.direct_out && off != ~0ull && off + nb <= w.out_cap;
-	if(c.direct_out && off != ~0ull && !place && tid == 0) atomicOr(w.status, 2u);
+	const bool late = c.direct_out && off == ~0ull;   // its place was not known in time: into the slot, moved later
+	const bool place = c.direct_out && !late && off + nb <= w.out_cap;
+	if(c.direct_out && !late && !place && tid == 0) atomicOr(w.status, 2u);
 	uint8_t *dst = place ? w.out + off : slot;
+	if(late) {
+		for(uint32_t i = tid; i < full; i += PF_THREADS) slot_words[i] = __builtin_bswap32(bitbuf[i]);
+		if(tid == 0) ((uint32_t*)(w.lb + c.F))[f] = 1u;   // the list of late frames follows the look-back states
+	}
 	if(tid == 0) {
 		uint32_t crc = sh.crc_acc;
 		const uint32_t last = bitbuf[full];
-		const bool store = place || !c.direct_out;
+		const bool store = place || !c.direct_out || late;
 		for(uint32_t i = 0; i < tail_bytes; i++) {
 			const uint32_t byte = (last >> (24u - 8u * i)) & 0xffu;
 			if(store) dst[full * 4u + i] = (uint8_t)byte;
@@ -1003,10 +1011,28 @@ __global__ void __launch_bounds__(1024) fa_scan_kernel(FaCfg c, FaWork w)
 	}
 }
 
-// One workgroup per frame: byte-granular destination, 4-byte loads where the source allows
+// One frame from its slot to its place, by a workgroup of 256: byte-granular destination, 4-byte loads where the source allows
+__device__ __forceinline__ void fa_move_frame(const FaCfg &c, const FaWork &w, uint32_t f, uint8_t *__restrict__ out, unsigned long long out_cap, uint32_t *__restrict__ frame_bytes_out);
+
 __global__ void __launch_bounds__(256) fa_gather_kernel(FaCfg c, FaWork w, uint8_t *__restrict__ out, unsigned long long out_cap, uint32_t *__restrict__ frame_bytes_out)
 {
-	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	fa_move_frame(c, w, blockIdx.x, out, out_cap, frame_bytes_out);
+}
+
+// After a pack kernel that wrote its frames in place: the frames that went to their slots because their place was not
+// known in time (FaWork::lb, the flags behind the look-back states), sixteen frames to a workgroup.  Normally none.
+__global__ void __launch_bounds__(256) fa_place_late_kernel(FaCfg c, FaWork w, uint8_t *__restrict__ out, unsigned long long out_cap, uint32_t *__restrict__ frame_bytes_out)
+{
+	const uint32_t *late = (const uint32_t*)(w.lb + c.F);
+	for(uint32_t k = 0; k < 16u; k++) {
+		const uint32_t f = blockIdx.x * 16u + k;
+		if(f < c.F && late[f]) fa_move_frame(c, w, f, out, out_cap, frame_bytes_out);   // (the same for the whole workgroup)
+	}
+}
+
+__device__ __forceinline__ void fa_move_frame(const FaCfg &c, const FaWork &w, uint32_t f, uint8_t *__restrict__ out, unsigned long long out_cap, uint32_t *__restrict__ frame_bytes_out)
+{
+	const uint32_t tid = threadIdx.x;
 	const uint32_t nb = w.frame_bytes[f];
 	const unsigned long long off = w.offsets[f] + (c.multi == 2u ? w.frame_shift[f] : 0u);
 	if(tid == 0 && frame_bytes_out) frame_bytes_out[f] = nb;
@@ -1114,6 +1140,8 @@ extern "C" void fa_launch_pack_general(const void *pcm, const FaCfg *c, const Fa
 extern "C" void fa_launch_offsets(const FaCfg *c, const FaWork *w, hipStream_t st)
 {
 	hipLaunchKernelGGL(fa_scan_kernel, dim3((c->F + 1023u) / 1024u), dim3(1024), 0, st, *c, *w);
+	// frames written in place: those that went to their slots instead now have their offsets
+	if(c->direct_out) hipLaunchKernelGGL(fa_place_late_kernel, dim3((c->F + 15u) / 16u), dim3(256), 0, st, *c, *w, w->out, (unsigned long long)w->out_cap, w->frame_bytes_out);
 }
 
 // can the pack stage put the frames of this batch straight into the caller's buffer?

@@ -233,13 +233,15 @@ def test_stress_signals_on_the_register_resident_path(gpu_engine, kind, level, b
         enc.close()
 
 
-@pytest.mark.parametrize("flag", [0x80000, 0x40000, 0xC0000, 0x100000])
+@pytest.mark.parametrize("flag", [0x80000, 0x40000, 0xC0000, 0x100000, 0x20000000])
 def test_alternative_stage_arrangements_give_the_same_frames(gpu_engine, monkeypatch, flag):
     """The register-resident kernels take shortcuts that other configurations cannot: the pack kernel writes frames
     at their final place (look-back over the frame sizes) instead of into slots for the gather kernel, the search
     kernel takes the fixed predictors' partition sums from the preparation pass instead of computing them, and the
     preparation kernel for full-length frames takes the frame totals from those partition sums.  The development
-    switches that turn each of them off must not change a byte."""
+    switches that turn each of them off must not change a byte.  Nor must the last switch, which sends every third
+    frame down the path of a frame whose place was not known in time: into its slot and from there to its place by
+    the pass that follows the pack kernel."""
     from flac_amd import synth
     pcm = synth.music_like(3.0, seed=91).astype(np.int16)
     for level in (8, 5, 2):
