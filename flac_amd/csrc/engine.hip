@@ -764,7 +764,11 @@ extern "C" int flacamd_encode_clips_device(flacamd_encoder *e, const void *d_pcm
 	hipStream_t st = (hipStream_t)stream;
 	HIP_TRY(hipSetDevice(e->device));
 	if(!e->md5s) {
-		HIP_TRY(hipStreamCreateWithFlags(&e->md5s, hipStreamNonBlocking));
+		// a stream of another priority than the caller's: streams of one priority take the process's few hardware queues in
+		// turn, and a hash as long as the longest clip must not sit in front of another encoder's kernels in the same queue
+		int least = 0, greatest = 0;
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIP_TRY(hipStreamCreateWithPriority(&e->md5s, hipStreamNonBlocking, greatest));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_tab, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_md5, hipEventDisableTiming));
 	}
