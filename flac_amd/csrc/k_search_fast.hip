@@ -12,11 +12,10 @@
 //                       take two taps per instruction (v_dot2_i32_i16 on packed pairs) and
 //                       |x - pred| accumulates in one instruction (v_sad_u32); one LDS atomic per
 //                       thread and candidate into the 64 finest-partition sums
-//   evaluation phase    one WAVE per candidate, no barriers and no atomics: lane p holds the sum
-//                       of finest partition p, six shuffle-add steps build the sums of every
-//                       coarser partition order in place, every lane prices the partitions it
-//                       owns (Rice parameter, bits), a halving butterfly totals the bits per
-//                       order, the best order is chosen and its parameters parked in LDS
+//   evaluation phase    eight lanes per candidate, no barriers and no atomics: lane j of a group adds the
+//                       finest partitions 8j .. 8j + 7 up to the partitions of the next three orders and prices
+//                       all fifteen, three exchange steps inside the group give the sums of the three coarsest
+//                       orders, the bits per order are summed over the group and the best order is chosen
 //   first wave          ordered arg-min over the candidates (estimate, then index: the
 //                       reference's strict-'<' keep-first rule) and the winner record
 //
@@ -95,7 +94,7 @@ __device__ __forceinline__ void sf_body(const void *__restrict__ pcm, const FaCf
 	const uint32_t n = c.N;
 	if(c.multi && w.frame_len[f] != n) return;   // a stream's short final block: the general kernel codes it
 	const uint64_t base = (uint64_t)f * c.N;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t i0 = tid * SF_CH;
 	const uint32_t wasted = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.wasted[g]);
 	const uint32_t ncand = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.ncand[g]);
