@@ -179,3 +179,43 @@ def test_queued_batches_equal_the_synchronous_call(gpu_engine):
         enc.encode_device_queue(d.data_ptr(), gpu_engine.PCM_S16, per * 4096, outs[0].data_ptr(), cap, fbs[0].data_ptr(), final=False)
     assert len(enc.wait()) == 16
     enc.close()
+
+
+def test_encoders_sharing_the_gpu_give_the_same_frames(gpu_engine):
+    """Several encoders coding at once on one GPU from threads of their own: their pack kernels share the CUs, and a
+    frame whose predecessors' sizes are late goes through its slot instead of waiting (fa_place_late_kernel).  Every
+    pass of every encoder must give the bytes a pass alone gives."""
+    import threading
+    import torch
+    pcm = np.tile(synth.music_like(20.0, seed=12).astype(np.int16), (6, 1))
+    n = len(pcm)
+    F = (n + 4095) // 4096
+    p = gpu_engine.make_params(2, 16, 44100, level=8)
+    d = torch.from_numpy(pcm).cuda()
+
+    def run(enc, out, fb, stream):
+        total = enc.encode_device(d.data_ptr(), gpu_engine.PCM_S16, n, out.data_ptr(), out.numel(), fb.data_ptr(), stream=stream.cuda_stream)
+        return bytes(out[:total].cpu().numpy()), fb.cpu().numpy().copy()
+
+    encs = [gpu_engine.Encoder(p, max_frames=F) for _ in range(4)]
+    bufs = [(torch.empty(encs[0].max_output_bytes(F), dtype=torch.uint8, device="cuda"), torch.zeros(F, dtype=torch.int32, device="cuda"), torch.cuda.Stream()) for _ in encs]
+    want = run(encs[0], *bufs[0])
+    assert want[1].sum() == len(want[0])
+    results = [[] for _ in encs]
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        for _ in range(6):
+            results[k].append(run(encs[k], *bufs[k]))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(encs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in encs:
+        e.close()
+    for k in range(len(encs)):
+        assert len(results[k]) == 6
+        for got in results[k]:
+            assert got[0] == want[0] and np.array_equal(got[1], want[1])
