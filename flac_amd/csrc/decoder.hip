@@ -19,6 +19,7 @@
 // (about one per 2^23 bytes of compressed audio) cost one wasted lane each.
 #include "engine_types.h"
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -496,7 +497,8 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 			const bool coded = ok && type >= 2u;
 			uint32_t todo = (ok && type != 0u) ? nres : 0u;
 			uint32_t mode = todo == 0u ? (uint32_t)M_IDLE : (type == 1u ? (uint32_t)M_VERB : (uint32_t)M_HDR);
-			uint32_t left = todo, part = 0, k = 0, raw = 0, qacc = 0;
+			uint32_t left = coded ? 0u : todo, part = 0, k = 0, raw = 0, qacc = 0;   // residuals left in the partition: none before its header
+			bool after_wait = false;
 			const uint32_t left_first = coded ? ((po == 0u) ? n - order : (n >> po) - order) : 0u, left_other = n >> po;   // samples of the first / of any later partition
 			const uint32_t hdr_shift = 32u - plen;
 			// the window as two words; the reader object is brought up to date again after the loop
@@ -530,7 +532,60 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 				}
 				int32_t *pp = &pipe.buf[pb][np][lane];   // where the next value goes
 				const bool general = __any((mode == (uint32_t)M_RAWHDR || mode == (uint32_t)M_RAW) ? 1 : 0) != 0;   // escape partitions: allowed by the format, not written by the reference encoder
-				if(!general) {
+				// Nearly every phase finds every lane at a partition header, at a Rice token that lies within the upper word
+				// of the window, or at a verbatim sample.  The step for that needs no mode: a lane of a coded subframe is at a
+				// header exactly when no residual of its partition is left.  A lane that meets anything else (a token that
+				// runs on into the next word, an escape code) takes nothing and sits the rest of the phase out; the phase after
+				// it is then the one below that knows everything.
+				const bool plain = !general && !after_wait && !(c.debug & 4u)
+					&& !__any((mode == (uint32_t)M_LOW || (mode == (uint32_t)M_TOKEN && qacc != 0u)) ? 1 : 0);
+				after_wait = false;
+				if(plain) {
+					const bool ran = mode != (uint32_t)M_IDLE, verb = mode == (uint32_t)M_VERB;
+					bool run = ran;
+					int32_t *const pp0 = pp;
+					uint32_t left_h = part == 0u ? left_first : left_other;   // what the next header of this lane sets
+					const uint32_t vsh = 32u - bps;
+#pragma unroll 2
+					for(uint32_t step = 0; step < FD_K; step++) {
+						const bool need = wav <= 32u;
+						const uint32_t wsw = need ? __builtin_bswap32(nextw) : 0u;
+						const unsigned long long ins = (unsigned long long)wsw << ((32u - wav) & 63u);   // (nothing to shift when no word is due)
+						whi |= (uint32_t)(ins >> 32); wlo |= (uint32_t)ins;
+						wav = need ? wav + 32u : wav; widx += need ? 1u : 0u;
+						nextw = br.ring[widx & (FD_RING_WORDS - 1u)][lane];
+						const bool hdr = left == 0u;   // (never for a verbatim subframe: its count is that of all its samples)
+						const uint32_t lz = (uint32_t)__clz((int)whi);   // 32 for an empty word
+						const uint32_t t1 = lz + k;
+						const bool fits = t1 <= 31u;
+						const uint32_t fld = __builtin_amdgcn_ubfe(whi, 31u - t1, k);   // (the instruction takes the offset modulo 32)
+						const uint32_t u = (lz << k) | fld;
+						const int32_t rice = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
+						const uint32_t kh = whi >> hdr_shift;
+						const bool seth = run && hdr && kh < esc;
+						const bool emit_b = run && !hdr && (verb || fits);
+						run = seth || emit_b;
+						if(SUBINFO) { if(sub && seth && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh; }
+						uint32_t take = verb ? bps : t1 + 1u;
+						take = hdr ? plen : take;
+						take = run ? take : 0u;
+						k = seth ? kh : k;
+						left = seth ? left_h : left;
+						left_h = seth ? left_other : left_h;
+						part += seth ? 1u : 0u;
+						left -= emit_b ? 1u : 0u;
+						todo -= emit_b ? 1u : 0u;
+						run = run && todo != 0u;
+						*pp = verb ? (int32_t)whi >> vsh : rice; pp += emit_b ? 64 : 0;
+						const unsigned long long wv = (((unsigned long long)whi << 32) | wlo) << take;   // take <= 32
+						whi = (uint32_t)(wv >> 32); wlo = (uint32_t)wv;
+						wav -= take;
+					}
+					np += (uint32_t)(pp - pp0) >> 6;
+					if(ran) mode = todo == 0u ? (uint32_t)M_IDLE : (verb ? (uint32_t)M_VERB : (left == 0u ? (uint32_t)M_HDR : (uint32_t)M_TOKEN));
+					after_wait = __any((ran && !run && todo != 0u) ? 1 : 0) != 0;
+				}
+				else if(!general) {
 #pragma unroll 2
 					for(uint32_t step = 0; step < FD_K; step++) {
 						// refill: one more word when 32 bits or fewer are left
@@ -690,15 +745,27 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 			bool done = false;
 			{
 				const bool lane_fast = st == 5u && type >= 1u && in_regs && cnt <= nres && i + cnt <= n;   // verbatim samples pass as residuals of an all-zero predictor
-				if(!(c.debug & 1u) && !__any((cnt != 0u && !lane_fast) ? 1 : 0)) {
+				// One buffer of residuals for every lane.  NARROW: the history as signed 16-bit halves and nothing else - six
+				// v_dot2 per sample instead of twelve - for subframes on the reference's 32-bit routine (`wide` clear: the sum
+				// may wrap, and wraps the same way here) whose samples all lie within 16 bits, looked at before and afterwards
+				// like the bound of the other form.  Returns whether the state was taken over.
+				auto fast_buffer = [&](auto narrow_c) -> bool {
+					constexpr bool NARROW = decltype(narrow_c)::value;
 					uint32_t hl[FD_REGORD / 2], hh[FD_REGORD / 2], mag = 0;
 #pragma unroll
 					for(int t = 0; t < FD_REGORD / 2; t++) {
 						const uint32_t a = (uint32_t)hr[2 * t], b = (uint32_t)hr[2 * t + 1];
-						hl[t] = __builtin_amdgcn_perm(b, a, 0x05040100u) ^ 0x80008000u;
-						hh[t] = __builtin_amdgcn_perm(b, a, 0x07060302u);
-						mag |= (a ^ (uint32_t)((int32_t)a >> 31)) | (b ^ (uint32_t)((int32_t)b >> 31));
+						if constexpr(NARROW) {
+							hl[t] = __builtin_amdgcn_perm(b, a, 0x05040100u); hh[t] = 0;
+							mag |= (a + 0x8000u) | (b + 0x8000u);
+						}
+						else {
+							hl[t] = __builtin_amdgcn_perm(b, a, 0x05040100u) ^ 0x80008000u;
+							hh[t] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+							mag |= (a ^ (uint32_t)((int32_t)a >> 31)) | (b ^ (uint32_t)((int32_t)b >> 31));
+						}
 					}
+					if constexpr(NARROW) { if(__any((cnt != 0u && mag >= 0x10000u) ? 1 : 0)) return false; }
 					const int32_t *src = &pipe.buf[p][0][lane];
 					// Every lane writes its own row, so a store instruction touches 64 cache lines whatever its width: samples are
 					// kept until four that share an aligned 16 bytes are together and go out in one store.  Samples whose four
@@ -707,43 +774,70 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					uint32_t pm = i & 3u;             // place of the next sample within its four
 					int32_t *dst = out + i;
 					for(uint32_t j = 0; j < cnt; j++) {   // lanes leave as their items run out; nothing in here needs the whole wave
-						{
-							const int32_t v = *src; src += 64;
+						const int32_t v = *src; src += 64;
+						int32_t pred;
+						if constexpr(NARROW) {
+							int32_t a0 = fd_dot2(qp[0], hl[0], 0), a1 = fd_dot2(qp[1], hl[1], 0);
+							a0 = fd_dot2(qp[2], hl[2], a0); a1 = fd_dot2(qp[3], hl[3], a1);
+							a0 = fd_dot2(qp[4], hl[4], a0); a1 = fd_dot2(qp[5], hl[5], a1);
+							pred = (int32_t)((uint32_t)a0 + (uint32_t)a1) >> shift;
+						}
+						else {
 							int32_t a0 = fd_dot2(qp[0], hl[0], -1), a1 = fd_dot2(qp[2], hl[2], -1), a2 = fd_dot2(qp[4], hl[4], -1), sh = fd_dot2(qp[0], hh[0], 0);
 							a0 = fd_dot2(qp[1], hl[1], a0); a1 = fd_dot2(qp[3], hl[3], a1); a2 = fd_dot2(qp[5], hl[5], a2);
 #pragma unroll
 							for(int t = 1; t < FD_REGORD / 2; t++) sh = fd_dot2(qp[t], hh[t], sh);
 							const long long sum = (long long)a0 + (long long)a1 + (long long)a2 + bias + ((long long)sh << 16);
-							const int32_t pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum >> shift);
-							const int32_t x = (int32_t)((uint32_t)v + (uint32_t)pred);
+							pred = wide ? (int32_t)(sum >> shift) : ((int32_t)(uint32_t)sum >> shift);
+						}
+						const int32_t x = (int32_t)((uint32_t)v + (uint32_t)pred);
 #pragma unroll
-							for(int t = FD_REGORD / 2 - 1; t > 0; t--) { hl[t] = __builtin_amdgcn_alignbit(hl[t], hl[t - 1], 16); hh[t] = __builtin_amdgcn_alignbit(hh[t], hh[t - 1], 16); }
+						for(int t = FD_REGORD / 2 - 1; t > 0; t--) {
+							hl[t] = __builtin_amdgcn_alignbit(hl[t], hl[t - 1], 16);
+							if constexpr(!NARROW) hh[t] = __builtin_amdgcn_alignbit(hh[t], hh[t - 1], 16);
+						}
+						if constexpr(NARROW) {
+							hl[0] = __builtin_amdgcn_perm(hl[0], (uint32_t)x, 0x05040100u);
+							mag |= (uint32_t)x + 0x8000u;
+						}
+						else {
 							hl[0] = __builtin_amdgcn_perm(hl[0], (uint32_t)x ^ 0x8000u, 0x05040100u);
 							hh[0] = __builtin_amdgcn_perm(hh[0], (uint32_t)x, 0x05040302u);
 							mag |= (uint32_t)x ^ (uint32_t)(x >> 31);
-							const int32_t y = (int32_t)((uint32_t)x << wasted);
-							o0 = o1; o1 = o2; o2 = o3; o3 = y;
-							if(pm > j) *dst = y;                                                   // its four began before this buffer
-							else if(pm == 3u) *(int4*)(dst - 3) = make_int4(o0, o1, o2, o3);       // (j >= 3 here: the four are all of this buffer)
-							dst++; pm = (pm + 1u) & 3u;
 						}
+						const int32_t y = (int32_t)((uint32_t)x << wasted);
+						o0 = o1; o1 = o2; o2 = o3; o3 = y;
+						if(pm > j) *dst = y;                                                   // its four began before this buffer
+						else if(pm == 3u) *(int4*)(dst - 3) = make_int4(o0, o1, o2, o3);       // (j >= 3 here: the four are all of this buffer)
+						dst++; pm = (pm + 1u) & 3u;
 					}
 					if(pm <= cnt) {   // pm samples of an unfinished four (when it began in this buffer)
 						if(pm >= 1u) dst[-1] = o3;
 						if(pm >= 2u) dst[-2] = o2;
 						if(pm >= 3u) dst[-3] = o1;
 					}
-					if(!__any(mag >= (1u << 28) ? 1 : 0)) {
+					if(NARROW ? __any((cnt != 0u && mag >= 0x10000u) ? 1 : 0) : __any(mag >= (1u << 28) ? 1 : 0)) return false;
+					if(!NARROW || cnt != 0u) {   // (the narrow form looked at the histories of lanes with values only)
 #pragma unroll
 						for(int t = 0; t < FD_REGORD / 2; t++) {
-							const uint32_t lo = hl[t] ^ 0x80008000u;
-							hr[2 * t] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x05040100u);
-							hr[2 * t + 1] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x07060302u);
+							if constexpr(NARROW) {
+								hr[2 * t] = (int32_t)(hl[t] << 16) >> 16;
+								hr[2 * t + 1] = (int32_t)hl[t] >> 16;
+							}
+							else {
+								const uint32_t lo = hl[t] ^ 0x80008000u;
+								hr[2 * t] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x05040100u);
+								hr[2 * t + 1] = (int32_t)__builtin_amdgcn_perm(hh[t], lo, 0x07060302u);
+							}
 						}
-						i += cnt; nres -= cnt;
-						if(cnt != 0u && nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
-						done = true;
 					}
+					i += cnt; nres -= cnt;
+					if(cnt != 0u && nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
+					return true;
+				};
+				if(!(c.debug & 1u) && !__any((cnt != 0u && !lane_fast) ? 1 : 0)) {
+					if(!(c.debug & 2u) && !__any((cnt != 0u && wide) ? 1 : 0)) done = fast_buffer(std::true_type{});
+					if(!done) done = fast_buffer(std::false_type{});
 				}
 			}
 			if(!done) for(uint32_t j = 0; __any(j < cnt ? 1 : 0); j++) {
