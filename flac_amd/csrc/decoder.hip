@@ -546,29 +546,27 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					int32_t *const pp0 = pp;
 					uint32_t left_h = part == 0u ? left_first : left_other;   // what the next header of this lane sets
 					const uint32_t vsh = 32u - bps;
-#pragma unroll 2
-					for(uint32_t step = 0; step < FD_K; step++) {
-						const bool need = wav <= 32u;
-						const uint32_t wsw = need ? __builtin_bswap32(nextw) : 0u;
-						const unsigned long long ins = (unsigned long long)wsw << ((32u - wav) & 63u);   // (nothing to shift when no word is due)
-						whi |= (uint32_t)(ins >> 32); wlo |= (uint32_t)ins;
-						wav = need ? wav + 32u : wav; widx += need ? 1u : 0u;
-						nextw = br.ring[widx & (FD_RING_WORDS - 1u)][lane];
+					// one item off the window.  The second of a step has what the first left: it goes ahead when all its bits
+					// are there (a count of leading zeros that stays within them has found a real one), and otherwise leaves
+					// the item to the next step without that being held against the lane.
+					auto item = [&](auto second_c) {
+						constexpr bool SECOND = decltype(second_c)::value;
 						const bool hdr = left == 0u;   // (never for a verbatim subframe: its count is that of all its samples)
 						const uint32_t lz = (uint32_t)__clz((int)whi);   // 32 for an empty word
 						const uint32_t t1 = lz + k;
-						const bool fits = t1 <= 31u;
 						const uint32_t fld = __builtin_amdgcn_ubfe(whi, 31u - t1, k);   // (the instruction takes the offset modulo 32)
 						const uint32_t u = (lz << k) | fld;
 						const int32_t rice = (int32_t)(u >> 1) ^ -(int32_t)(u & 1u);
 						const uint32_t kh = whi >> hdr_shift;
-						const bool seth = run && hdr && kh < esc;
-						const bool emit_b = run && !hdr && (verb || fits);
-						run = seth || emit_b;
-						if(SUBINFO) { if(sub && seth && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh; }
 						uint32_t take = verb ? bps : t1 + 1u;
 						take = hdr ? plen : take;
-						take = run ? take : 0u;
+						const bool there = SECOND ? take <= wav : true;
+						const bool fits = verb || t1 <= 31u;
+						const bool seth = run && hdr && kh < esc && there;
+						const bool emit_b = run && !hdr && fits && there;
+						if constexpr(!SECOND) run = seth || emit_b;
+						if(SUBINFO) { if(sub && seth && part < FLACAMD_SUBINFO_PARTS) sub->rice[part] = (uint8_t)kh; }
+						take = (seth || emit_b) ? take : 0u;
 						k = seth ? kh : k;
 						left = seth ? left_h : left;
 						left_h = seth ? left_other : left_h;
@@ -580,6 +578,16 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 						const unsigned long long wv = (((unsigned long long)whi << 32) | wlo) << take;   // take <= 32
 						whi = (uint32_t)(wv >> 32); wlo = (uint32_t)wv;
 						wav -= take;
+					};
+					for(uint32_t step = 0; step < FD_K / 2u; step++) {
+						const bool need = wav <= 32u;
+						const uint32_t wsw = need ? __builtin_bswap32(nextw) : 0u;
+						const unsigned long long ins = (unsigned long long)wsw << ((32u - wav) & 63u);   // (nothing to shift when no word is due)
+						whi |= (uint32_t)(ins >> 32); wlo |= (uint32_t)ins;
+						wav = need ? wav + 32u : wav; widx += need ? 1u : 0u;
+						nextw = br.ring[widx & (FD_RING_WORDS - 1u)][lane];
+						item(std::false_type{});
+						item(std::true_type{});
 					}
 					np += (uint32_t)(pp - pp0) >> 6;
 					if(ran) mode = todo == 0u ? (uint32_t)M_IDLE : (verb ? (uint32_t)M_VERB : (left == 0u ? (uint32_t)M_HDR : (uint32_t)M_TOKEN));
@@ -835,8 +843,72 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					if(cnt != 0u && nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
 					return true;
 				};
+				// The same narrow form with the samples of a buffer taken in aligned fours (the four that go out in one
+				// store): the history is kept in both pair alignments - E[t] = samples 2t, 2t + 1 back, O[t] = samples
+				// 2t + 1, 2t + 2 back - so that a new sample only has to be paired with its neighbour and every other
+				// pair of the next history is a register that exists already; the samples before the first and after the
+				// last whole four are taken one by one.
+				auto narrow_fours = [&]() -> bool {
+					uint32_t E[FD_REGORD / 2], mag = 0;
+#pragma unroll
+					for(int t = 0; t < FD_REGORD / 2; t++) {
+						const uint32_t a = (uint32_t)hr[2 * t], b = (uint32_t)hr[2 * t + 1];
+						E[t] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+						mag |= (a + 0x8000u) | (b + 0x8000u);
+					}
+					if(__any((cnt != 0u && mag >= 0x10000u) ? 1 : 0)) return false;
+					const int32_t *src = &pipe.buf[p][0][lane];
+					int32_t *dst = out + i;
+					auto predict = [&](uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t p4, uint32_t p5) {
+						int32_t a0 = fd_dot2(qp[0], p0, 0), a1 = fd_dot2(qp[1], p1, 0);
+						a0 = fd_dot2(qp[2], p2, a0); a1 = fd_dot2(qp[3], p3, a1);
+						a0 = fd_dot2(qp[4], p4, a0); a1 = fd_dot2(qp[5], p5, a1);
+						return (int32_t)((uint32_t)a0 + (uint32_t)a1) >> shift;
+					};
+					auto single = [&]() {
+						const int32_t v = *src; src += 64;
+						const int32_t x = (int32_t)((uint32_t)v + (uint32_t)predict(E[0], E[1], E[2], E[3], E[4], E[5]));
+#pragma unroll
+						for(int t = FD_REGORD / 2 - 1; t > 0; t--) E[t] = __builtin_amdgcn_alignbit(E[t], E[t - 1], 16);
+						E[0] = __builtin_amdgcn_perm(E[0], (uint32_t)x, 0x05040100u);
+						mag |= (uint32_t)x + 0x8000u;
+						*dst++ = (int32_t)((uint32_t)x << wasted);
+					};
+					uint32_t j = 0;
+					for(; j < cnt && (((uint32_t)i + j) & 3u) != 0u; j++) single();
+					if(j + 4u <= cnt) {
+						uint32_t O[FD_REGORD / 2 - 1];
+#pragma unroll
+						for(int t = 0; t < FD_REGORD / 2 - 1; t++) O[t] = __builtin_amdgcn_alignbit(E[t + 1], E[t], 16);
+						for(; j + 4u <= cnt; j += 4u) {
+							const int32_t v0 = src[0], v1 = src[64], v2 = src[128], v3 = src[192]; src += 256;
+							const int32_t x0 = (int32_t)((uint32_t)v0 + (uint32_t)predict(E[0], E[1], E[2], E[3], E[4], E[5]));
+							const uint32_t n0 = __builtin_amdgcn_perm(E[0], (uint32_t)x0, 0x05040100u);          // (x0, the sample before it)
+							const int32_t x1 = (int32_t)((uint32_t)v1 + (uint32_t)predict(n0, O[0], O[1], O[2], O[3], O[4]));
+							const uint32_t e0 = __builtin_amdgcn_perm((uint32_t)x0, (uint32_t)x1, 0x05040100u);   // (x1, x0)
+							const int32_t x2 = (int32_t)((uint32_t)v2 + (uint32_t)predict(e0, E[0], E[1], E[2], E[3], E[4]));
+							const uint32_t n1 = __builtin_amdgcn_perm(e0, (uint32_t)x2, 0x05040100u);             // (x2, x1)
+							const int32_t x3 = (int32_t)((uint32_t)v3 + (uint32_t)predict(n1, n0, O[0], O[1], O[2], O[3]));
+							const uint32_t e1 = __builtin_amdgcn_perm((uint32_t)x2, (uint32_t)x3, 0x05040100u);   // (x3, x2)
+							E[5] = E[3]; E[4] = E[2]; E[3] = E[1]; E[2] = E[0]; E[1] = e0; E[0] = e1;
+							O[4] = O[2]; O[3] = O[1]; O[2] = O[0]; O[1] = n0; O[0] = n1;
+							mag |= ((uint32_t)x0 + 0x8000u) | ((uint32_t)x1 + 0x8000u) | ((uint32_t)x2 + 0x8000u) | ((uint32_t)x3 + 0x8000u);
+							*(int4*)dst = make_int4((int32_t)((uint32_t)x0 << wasted), (int32_t)((uint32_t)x1 << wasted), (int32_t)((uint32_t)x2 << wasted), (int32_t)((uint32_t)x3 << wasted));
+							dst += 4;
+						}
+					}
+					for(; j < cnt; j++) single();
+					if(__any((cnt != 0u && mag >= 0x10000u) ? 1 : 0)) return false;
+					if(cnt != 0u) {   // (only the histories of lanes with values were looked at)
+#pragma unroll
+						for(int t = 0; t < FD_REGORD / 2; t++) { hr[2 * t] = (int32_t)(E[t] << 16) >> 16; hr[2 * t + 1] = (int32_t)E[t] >> 16; }
+					}
+					i += cnt; nres -= cnt;
+					if(cnt != 0u && nres == 0u) { ch++; st = ch == c.channels ? 6u : 1u; }
+					return true;
+				};
 				if(!(c.debug & 1u) && !__any((cnt != 0u && !lane_fast) ? 1 : 0)) {
-					if(!(c.debug & 2u) && !__any((cnt != 0u && wide) ? 1 : 0)) done = fast_buffer(std::true_type{});
+					if(!(c.debug & 2u) && !__any((cnt != 0u && wide) ? 1 : 0)) done = (c.debug & 8u) ? fast_buffer(std::true_type{}) : narrow_fours();
 					if(!done) done = fast_buffer(std::false_type{});
 				}
 			}
@@ -956,14 +1028,17 @@ __global__ void __launch_bounds__(FD_CRC_THREADS) fd_crc_kernel(const uint8_t *_
 			// aligned words covering [pos + start, pos + start + seg): seg / 4 + 1 of them
 			const uint64_t a = pos + (uint64_t)start, a0 = a & ~(uint64_t)3;
 			const uint32_t sh = (uint32_t)(a & 3u) * 8u, nw = seg / 4u;
-			uint32_t wv[FD_CRC_MAXWORDS + 1];
+			// four words to a load: the segments of a wave's threads lie crc_seg_bytes apart, so a load instruction touches
+			// some forty cache lines whatever its width, and the lookups of those lines are what the kernel waits for
+			typedef uint32_t fd_words4 __attribute__((ext_vector_type(4), aligned(4)));
+			uint32_t wv[FD_CRC_MAXWORDS + 4];
 #pragma unroll
-			for(int j = 0; j <= FD_CRC_MAXWORDS; j++) {
-				wv[j] = 0;
-				if((uint32_t)j <= nw) {
-					const uint64_t o = a0 + 4u * (uint32_t)j;
-					if(o + 4u <= c.nbytes) wv[j] = *(const uint32_t*)(bytes + o);
-					else { for(uint32_t m = 0; m < 4u; m++) if(o + m < c.nbytes) wv[j] |= (uint32_t)bytes[o + m] << (8u * m); }
+			for(int jj = 0; jj <= FD_CRC_MAXWORDS / 4; jj++) {
+				wv[4 * jj] = 0; wv[4 * jj + 1] = 0; wv[4 * jj + 2] = 0; wv[4 * jj + 3] = 0;
+				if(4u * (uint32_t)jj <= nw) {
+					const uint64_t o = a0 + 16u * (uint32_t)jj;
+					if(o + 16u <= c.nbytes) { const fd_words4 v = *(const fd_words4*)(bytes + o); wv[4 * jj] = v.x; wv[4 * jj + 1] = v.y; wv[4 * jj + 2] = v.z; wv[4 * jj + 3] = v.w; }
+					else { for(uint32_t m = 0; m < 16u; m++) if(o + m < c.nbytes) wv[4 * jj + (m >> 2)] |= (uint32_t)bytes[o + m] << (8u * (m & 3u)); }
 				}
 			}
 #pragma unroll
