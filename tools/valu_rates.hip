@@ -72,6 +72,22 @@ __global__ void __launch_bounds__(256) k_mad64(long long *out, int a, int b) {
 	out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
+// one dependent chain: every instruction takes the result of the one before it
+#define DEF_KERNEL_DEP(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(int *out, int a, int b) { \
+	int x0 = threadIdx.x; \
+	int va = a + threadIdx.x, vb = b ^ threadIdx.x; \
+	for(int i = 0; i < ITERS; i++) { \
+		asm volatile(ASM(%0) "\n" ASM(%0) "\n" ASM(%0) "\n" ASM(%0) "\n" ASM(%0) "\n" ASM(%0) "\n" ASM(%0) "\n" ASM(%0) \
+			: "+v"(x0) : "v"(va), "v"(vb)); \
+	} \
+	out[blockIdx.x * 256 + threadIdx.x] = x0; \
+}
+#define D_MAD24(x) "v_mad_i32_i24 " #x ", %1, %2, " #x
+#define D_ADD(x) "v_add_u32 " #x ", %1, " #x
+DEF_KERNEL_DEP(k_mad24_dep, D_MAD24)
+DEF_KERNEL_DEP(k_add_dep, D_ADD)
+
 // 64-bit and packed-float instructions: four independent chains on register pairs
 #define DEF_KERNEL64(NAME, ASM) \
 __global__ void __launch_bounds__(256) NAME(long long *out, int a, int b) { \
@@ -132,6 +148,23 @@ static void run(const char *name, K kern, T *buf)
 	printf("%-12s %8.3f ms  %6.2f ns per wave-instr per SIMD  (= %5.2f cycles at the measured %.3f GHz)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * g_ghz, g_ghz);
 }
 
+// the same loops with `waves` waves on every SIMD: what a wave gets when it has the SIMD (nearly) to itself
+template<typename K>
+static void run_few(const char *name, K kern, int *buf, int waves)
+{
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const int blocks = 256 * waves;
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, buf, 3, 5);
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, buf, 3, 5);
+	hipEventRecord(e1, 0);
+	hipEventSynchronize(e1);
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	const double per_wave = ITERS * 8.0;
+	printf("%-28s %d wave(s) per SIMD  %8.3f ms  %6.2f cycles per instruction of one wave, %5.2f per wave-instr per SIMD\n", name, waves, ms, ms * 1e6 / per_wave * g_ghz, ms * 1e6 / per_wave * g_ghz / waves);
+}
+
 int main()
 {
 	int *buf; hipMalloc(&buf, 256 * 8 * 256 * 8);
@@ -159,5 +192,9 @@ int main()
 	run("alignbit_b32", k_alignbit, buf); run("perm_b32", k_perm, buf); run("bfe_i32", k_bfe, buf); run("mov_b32", k_mov, buf); run("xor_b32", k_xor, buf);
 	run("ashrrev_i64", k_ashr64, (long long*)buf); run("lshl_add_u64", k_lshladd64, (long long*)buf);
 	run("pk_mul_f32", k_pkmulf, (long long*)buf); run("pk_add_f32", k_pkaddf, (long long*)buf); run("pk_fma_f32", k_pkfmaf, (long long*)buf); run("fma_f64", k_fma64, (long long*)buf);
+	for(int waves = 1; waves <= 4; waves *= 2) {
+		run_few("mad_i32_i24, 8 chains", k_mad24, buf, waves); run_few("mad_i32_i24, 1 chain", k_mad24_dep, buf, waves);
+		run_few("add_u32, 8 chains", k_add, buf, waves); run_few("add_u32, 1 chain", k_add_dep, buf, waves);
+	}
 	return 0;
 }
