@@ -46,7 +46,7 @@ struct FdWork {
 	uint32_t *ncand;        // [1]
 	uint64_t *cand_pos;     // [max_frames]
 	uint64_t *cand_end;     // [max_frames] byte just past the frame
-	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bits 4..7 assignment (0..3), bits 8..11 why parsing stopped
+	uint32_t *cand_info;    // [max_frames] bit0 parsed ok, bit1 crc ok, bit2 a predictor of more than FD_REGORD taps, bits 4..7 assignment (0..3), bits 8..11 why parsing stopped
 	uint32_t *cand_bs;      // [max_frames]
 	uint64_t *cand_num;     // [max_frames] frame or sample number from the header
 	int32_t  *ws;           // [max_frames][channels][ws_stride] subframe outputs before decorrelation
@@ -396,7 +396,8 @@ struct FdPipe {
 // LONGPRED: with room in LDS for predictors of more than FD_REGORD taps (only streams outside the subset have them:
 // `flac --lax -l 32`).  That room is 16 KB of 53, and the LDS is what bounds the number of workgroups on a compute unit,
 // so a decode starts with the kernel without it; a lane of that kernel that meets such a predictor leaves its subframe
-// alone and raises a flag, and the host then runs the pass again with the other kernel and stays with it.
+// alone and marks its candidate, and when such a candidate turns out to be a frame (CRC-16 and chain) the host runs the
+// pass again with the other kernel and stays with it.
 template<bool SUBINFO, bool LONGPRED>
 __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__restrict__ bytes, FdCfg c, FdWork w)
 {
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 		const bool parsed_header = ok;
 		const uint32_t n = h.blocksize;
 		BitReader br; br.init(bytes, c.nbytes, ok ? pos + h.hdr_bytes : 0, s_ring, lane);
-		uint32_t ex = 0;
+		uint32_t ex = 0, long_pred = 0;
 		uint4 pf0 = make_uint4(0u, 0u, 0u, 0u), pf1 = pf0, pf2 = pf0, pf3 = pf0; uint32_t pf_at = 0; bool pf_valid = false;   // 64 bytes of the stream on their way to the ring
 		if(ok) push((int32_t)n);
 		for(uint32_t ch = 0; ch < c.channels; ch++) {
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 					// there; the frame still parses the same way, so go on for the sake of its length
 					shift = sh < 0 ? 0u : (uint32_t)sh;
 					for(uint32_t j = 0; j < order; j++) { br.top_up(); const int16_t qv = (int16_t)br.read_signed(prec); if(j < QROWS) s_q[j][lane] = qv; if(sub) sub->q[j] = qv; }
-					if(!LONGPRED && order > (uint32_t)FD_REGORD) w.ncand[1] = 1u;   // see above; every lane that writes writes the same
+					if(order > (uint32_t)FD_REGORD) { long_pred = 4u; if(!LONGPRED) w.ncand[1] = 1u; }   // see above; every lane that writes writes the same
 					wide = (bps + prec + fa_ilog2(order) <= 32u) ? 0u : 1u;                    // :2682
 				}
 				const uint32_t method = br.read(2);
@@ -720,7 +721,7 @@ __global__ void __launch_bounds__(128) fd_decode_pipe_kernel(const uint8_t *__re
 			// cand_end: the byte just past the frame, or where the reference would look for the next sync code
 			// after giving the frame up (frame_sync_ first skips to the byte boundary, :1961-1965)
 			w.cand_end[ci] = (br.bitpos() + 7u) >> 3; w.cand_bs[ci] = n; w.cand_num[ci] = h.number;
-			w.cand_info[ci] = (ok ? 1u : 0u) | (h.assignment << 4) | (ex << 8);
+			w.cand_info[ci] = (ok ? 1u : 0u) | long_pred | (h.assignment << 4) | (ex << 8);
 		}
 	}
 	else {
@@ -1089,11 +1090,11 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 	__shared__ uint32_t wave_has[16];
 	__shared__ unsigned long long carry_a, carry_b, carry_end;
 	__shared__ uint32_t carry_has;
-	__shared__ uint32_t s_err;
+	__shared__ uint32_t s_err, s_long;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint32_t ncand_raw = w.ncand[0];
 	const uint32_t ncand = ncand_raw < c.max_frames ? ncand_raw : c.max_frames;
-	if(tid == 0) { carry_a = 0; carry_b = 0; carry_end = 0; carry_has = 0; s_err = ncand_raw > c.max_frames ? 4u : 0u; }
+	if(tid == 0) { carry_a = 0; carry_b = 0; carry_end = 0; carry_has = 0; s_err = ncand_raw > c.max_frames ? 4u : 0u; s_long = 0u; }
 	__syncthreads();
 	for(uint32_t base = 0; base < ncand; base += 1024u * FD_CHAIN_PER) {
 		const uint32_t i0 = base + tid * FD_CHAIN_PER;
@@ -1111,6 +1112,7 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 		for(uint32_t k = 0; k < FD_CHAIN_PER; k++) if((info[k] & 3u) == 3u) {
 			if(cnt == 0) first_pos = pos[k]; else if(pos[k] != last_end) breaks = 1u;
 			last_end = end[k]; cnt++; sum += bs[k];
+			if(info[k] & 4u) s_long = 1u;   // (every thread that writes writes the same)
 		}
 		unsigned long long ia = cnt, ib = sum;
 #pragma unroll
@@ -1152,7 +1154,7 @@ __global__ void __launch_bounds__(1024) fd_chain_kernel(FdCfg c, FdWork w)
 		w.result[4] = err;
 		w.result[5] = nframes ? w.cand_pos[w.frame_of[0]] : 0;
 		w.result[6] = ncand_raw;
-		w.result[7] = w.ncand[1];
+		w.result[7] = (w.ncand[1] ? 1u : 0u) | (s_long ? 2u : 0u);   // a predictor too long for the first decode kernel was met; ... in a frame that was accepted
 	}
 }
 
@@ -1370,8 +1372,11 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 		FD_TRY(hipGetLastError());
 		FD_TRY(hipMemcpyAsync(res, d->work.result, sizeof res, hipMemcpyDeviceToHost, st));
 		FD_TRY(hipStreamSynchronize(st));
-		if(!res[7] || d->long_predictors) break;
-		d->long_predictors = 1;   // a predictor of more than FD_REGORD taps was met: once more, with the kernel that has room for them
+		// a predictor of more than FD_REGORD taps in a frame that was accepted: once more, with the kernel that has room for them.
+		// (Met only by candidates that were turned down - false sync codes parse as anything - the pass stands: what the
+		// kernel restored for those is not used, and the slower kernel is not taken up on their account.)
+		if((res[7] & 3u) != 3u || d->long_predictors) break;
+		d->long_predictors = 1;
 	}
 	if(h_info) { h_info[0] = res[0]; h_info[1] = res[1]; h_info[2] = res[2]; h_info[3] = res[3]; }
 	if(res[4] & 8u) return FLACAMD_E_CAPACITY;

@@ -59,6 +59,24 @@ def test_decoder_handles_false_sync_codes(gpu_engine):
     assert info["frames"] == len(o["frames"]) and np.array_equal(out, pcm)
 
 
+def test_false_candidate_with_a_long_predictor(gpu_engine):
+    """Bytes behind the last frame that pass for a frame header whose first subframe claims a predictor of 32
+    taps: the candidate is turned down (it runs off the end), the frames before it decode as they are, and the
+    decoder does not go through the batch again on its account (stream_decoder.c:2611-2619 reads such a subframe;
+    the kernel with room for its history is only taken up for frames that are accepted)."""
+    lib = ob.oracle_lib()
+    g = load_golden("st16-level8")
+    blob = b"".join(g["frames"])
+    hdr = bytearray([0xFF, 0xF8, 0xC9, 0x18, 0x00])     # 4096 samples, 44.1 kHz, two independent channels, 16 bits, frame number 0
+    h = np.frombuffer(bytes(hdr), dtype=np.uint8).copy()
+    fake = bytes(hdr) + bytes([lib.fo_crc8(h.ctypes.data, len(h)), 0x7E]) + bytes(range(1, 120))   # 0x7E: LPC subframe of order 32
+    dec = gpu_engine.Decoder(2, 16, 4096, max_frames=64, max_bytes=len(blob) + len(fake))
+    for _ in range(2):   # the second call would run on the other kernel had the first switched to it: same result either way
+        pcm, info = dec.decode_host(blob + fake, len(g["pcm"]) + 4096)
+        assert info["frames"] == len(g["frames"]) and np.array_equal(pcm[: len(g["pcm"])], g["pcm"])
+    dec.close()
+
+
 def test_decoder_escape_partitions_and_rice2(gpu_engine):
     """Hand-built frames with an escaped (raw) partition and with 5-bit Rice parameters: this
     encoder never emits escapes, the decoder must still read them (stream_decoder.c:2764-2773)."""
