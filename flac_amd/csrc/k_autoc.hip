@@ -28,19 +28,25 @@
 
 // 16 raw wide samples of a stereo stream: PK = 1: one dword (left | right << 16) each (16-bit samples as they lie in a
 // 16-bit stream), PK = 2: two dwords (left, right) each (the 32-bit layout process_interleaved hands over)
-template<int PK> struct RawStereo { uint4 v[4 * PK]; };
+// ... and of a one-channel stream (MONO): PK = 1: eight dwords of two 16-bit samples, PK = 2: sixteen dwords
+template<int NV> struct RawStereo { uint4 v[NV]; };
 
-template<int PK>
-__device__ __forceinline__ uint32_t raw_dword(const RawStereo<PK> &r, int d)
+template<int NV>
+__device__ __forceinline__ uint32_t raw_dword(const RawStereo<NV> &r, int d)
 {
 	const uint4 &q = r.v[d >> 2];
 	return (d & 3) == 0 ? q.x : (d & 3) == 1 ? q.y : (d & 3) == 2 ? q.z : q.w;
 }
 
-// Fast path: stereo with mid/side analysis (signals L, R, M, S), blocksize a multiple of 16; PK as above.
-template<int LAG, int PK>
+// Fast path: stereo with mid/side analysis (signals L, R, M, S), or one channel (MONO: a lane per frame), blocksize a
+// multiple of 16; PK as above.  A batch of one-channel frames has a quarter of the lanes (an hour: 606 waves for 1024
+// SIMDs), so there the loads run two steps ahead: a wave with a SIMD to itself gets through a step in less time
+// than a load takes.
+template<int LAG, int PK, bool MONO = false>
 __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__restrict__ pcm, FaCfg c, FaWork w)
 {
+	constexpr int NV = MONO ? 2 * PK : 4 * PK;          // 16-byte loads per step
+	constexpr int DPS = MONO ? (PK == 1 ? 1 : 2) : 2 * PK;   // half dwords per sample: the step's AC_STEP samples take AC_STEP * DPS / 2 dwords
 	// These waves are few (one lane per signal) and each is a long serial chain: they go first wherever they share a SIMD
 	// with the preparation kernel's many short ones, which fill the gaps
 	__builtin_amdgcn_s_setprio(3);
@@ -48,10 +54,10 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const uint32_t g = blockIdx.x * 64u + lane;
 	const bool active = g < c.G;
 	const uint32_t gg = active ? g : c.G - 1u;
-	const uint32_t f = gg >> 2, s = gg & 3u;
+	const uint32_t f = MONO ? gg : gg >> 2, s = MONO ? 0u : gg & 3u;
 	const uint32_t n = fa_frame_len(c, w, f);
-	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N * (uint32_t)PK;   // dwords
-	const uint32_t f0 = (blockIdx.x * 64u) >> 2;
+	const uint32_t *__restrict__ p = pcm + (size_t)f * c.N * (uint32_t)DPS / 2u;   // dwords (the blocksize is a multiple of 16)
+	const uint32_t f0 = MONO ? blockIdx.x * 64u : (blockIdx.x * 64u) >> 2;
 	const uint32_t nloop = (!c.multi && f0 + 1 == c.F) ? c.last_n : c.N;   // short frames in between: their lanes add zeros past their end
 	// signal = (ca * left + cb * right) >> cs: L, R, (L+R)>>1, L-R (stream_encoder.c:2051-2058), wasted bits left in
 	const int32_t ca = (s == 1u) ? 0 : 1, cb = (s == 0u) ? 0 : (s == 3u ? -1 : 1);
@@ -59,18 +65,26 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 	const uint32_t cab = ((uint32_t)ca & 0xffffu) | ((uint32_t)cb << 16);   // the two factors as a pair of 16-bit halves
 
 	auto load16 = [&](uint32_t i0) {
-		RawStereo<PK> r;
+		RawStereo<NV> r;
 		if(i0 + AC_STEP <= n) {
-			const uint4 *q = (const uint4*)(p + (size_t)i0 * PK);
+			const uint4 *q = (const uint4*)(p + (size_t)i0 * DPS / 2u);
 #pragma unroll
-			for(int j = 0; j < 4 * PK; j++) r.v[j] = q[j];
+			for(int j = 0; j < NV; j++) r.v[j] = q[j];
 		}
 		else { // tail of a short last block: never read past the end of the stream
-			uint32_t t[AC_STEP * PK];
+			uint32_t t[4 * NV];
+			if constexpr(MONO && PK == 1) {
+				const uint16_t *h = (const uint16_t*)p + i0;
 #pragma unroll
-			for(int j = 0; j < AC_STEP * PK; j++) t[j] = (i0 + (uint32_t)(j / PK) < n) ? p[(size_t)i0 * PK + j] : 0u;
+				for(int j = 0; j < 4 * NV; j++) t[j] = ((i0 + 2u * j < n) ? (uint32_t)h[2 * j] : 0u) | ((i0 + 2u * j + 1u < n) ? (uint32_t)h[2 * j + 1] << 16 : 0u);
+			}
+			else {
+				constexpr int DW = DPS / 2;   // dwords per sample
 #pragma unroll
-			for(int j = 0; j < 4 * PK; j++) r.v[j] = make_uint4(t[4*j], t[4*j+1], t[4*j+2], t[4*j+3]);
+				for(int j = 0; j < 4 * NV; j++) t[j] = (i0 + (uint32_t)(j / DW) < n) ? p[(size_t)i0 * DW + j] : 0u;
+			}
+#pragma unroll
+			for(int j = 0; j < NV; j++) r.v[j] = make_uint4(t[4*j], t[4*j+1], t[4*j+2], t[4*j+3]);
 		}
 		return r;
 	};
@@ -93,14 +107,17 @@ __global__ void __launch_bounds__(64) fa_autoc_ms16_kernel(const uint32_t *__res
 		for(int i = 0; i < NP; i++) A[i] = (f2){0.0f, 0.0f};
 #pragma unroll
 		for(int i = 0; i < T / 2; i++) { E[i] = (f2){0.0f, 0.0f}; O[i] = (f2){0.0f, 0.0f}; }
-		RawStereo<PK> nxt = load16(0);
+		RawStereo<NV> nxt = load16(0), nxt2 = nxt;
+		if(MONO && AC_STEP < nloop) nxt2 = load16(AC_STEP);
 		for(uint32_t i0 = 0; i0 < nloop; i0 += AC_STEP) {
-			const RawStereo<PK> cur = nxt;
-			if(i0 + AC_STEP < nloop) nxt = load16(i0 + AC_STEP);
+			const RawStereo<NV> cur = nxt;
+			if constexpr(MONO) { nxt = nxt2; if(i0 + 2 * AC_STEP < nloop) nxt2 = load16(i0 + 2 * AC_STEP); }
+			else if(i0 + AC_STEP < nloop) nxt = load16(i0 + AC_STEP);
 #pragma unroll
 			for(int j = 0; j < AC_STEP; j++) {
 				int32_t x;
-				if(PK == 1) x = dot2_i16(raw_dword(cur, j), cab, 0) >> sh;   // ca * left + cb * right straight from the packed word: one instruction
+				if constexpr(MONO) x = PK == 1 ? (int32_t)(raw_dword(cur, j >> 1) << (16 * (1 - (j & 1)))) >> 16 : (int32_t)raw_dword(cur, j);
+				else if(PK == 1) x = dot2_i16(raw_dword(cur, j), cab, 0) >> sh;   // ca * left + cb * right straight from the packed word: one instruction
 				else {
 					const int32_t l = (int32_t)raw_dword(cur, 2 * j), r = (int32_t)raw_dword(cur, 2 * j + 1);
 					x = (int32_t)((uint32_t)ca * (uint32_t)l + (uint32_t)cb * (uint32_t)r) >> sh;   // (32-bit wrapping, like fa_signal)
@@ -220,6 +237,17 @@ extern "C" void fa_launch_autoc(const void *pcm, const FaCfg *c, const FaWork *w
 	else if(ms && c->pcm_format == FLACAMD_PCM_S32 && c->lag <= 13) {   // (lag 33 with 32 raw dwords in flight twice over would not fit the register file)
 		if(c->lag <= 9) hipLaunchKernelGGL((fa_autoc_ms16_kernel<9, 2>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
 		else hipLaunchKernelGGL((fa_autoc_ms16_kernel<13, 2>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+	}
+	else if(c->channels == 1u && c->nsig == 1u && (c->N % AC_STEP) == 0 && ((uintptr_t)pcm % 16u) == 0 && c->lag <= 13u
+		&& (c->pcm_format == FLACAMD_PCM_S16 || c->pcm_format == FLACAMD_PCM_S32) && !(c->debug & 0x10000000u)) {
+		if(c->pcm_format == FLACAMD_PCM_S16) {
+			if(c->lag <= 9) hipLaunchKernelGGL((fa_autoc_ms16_kernel<9, 1, true>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+			else hipLaunchKernelGGL((fa_autoc_ms16_kernel<13, 1, true>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		}
+		else {
+			if(c->lag <= 9) hipLaunchKernelGGL((fa_autoc_ms16_kernel<9, 2, true>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+			else hipLaunchKernelGGL((fa_autoc_ms16_kernel<13, 2, true>), grid, block, 0, st, (const uint32_t*)pcm, *c, *w);
+		}
 	}
 	else {
 		if(c->lag <= 9) hipLaunchKernelGGL(fa_autoc_kernel<9>, grid, block, 0, st, pcm, *c, *w);
