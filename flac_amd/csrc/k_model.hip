@@ -59,6 +59,11 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 	log2cmax--;
 	int shift = (int)pm1 - log2cmax - 1;
 	if(shift > 15) shift = 15; else if(shift < -16) return; // lpc.c:192-195 (return 1)
+	// the record is put together in registers and goes out in 16-byte stores: every lane writes its own signal's records,
+	// so a store instruction touches 64 cache lines whatever its width
+	uint32_t rec[((MAXORD + 4) / 4) * 4];
+#pragma unroll
+	for(int j = 0; j < ((MAXORD + 4) / 4) * 4; j++) rec[j] = 0;
 	double error = 0.0;
 	uint32_t sum_abs = 0;   // of the quantised coefficients (each below 2^15, at most 32 of them)
 	int32_t sum_q = 0;
@@ -70,7 +75,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			int32_t v = error >= 0.0 ? (int32_t)(error + 0.5) : (int32_t)(error - 0.5);
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
-			cw.coef((uint32_t)j, v);
+			rec[1 + j] = (uint32_t)v;
 			sum_abs += (uint32_t)(v < 0 ? -v : v); sum_q += v;
 		}
 	}
@@ -82,7 +87,7 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 			int32_t v = error >= 0.0 ? (int32_t)(error + 0.5) : (int32_t)(error - 0.5);
 			v = v > qmax ? qmax : (v < qmin ? qmin : v);
 			error -= (double)v;
-			cw.coef((uint32_t)j, v);
+			rec[1 + j] = (uint32_t)v;
 			sum_abs += (uint32_t)(v < 0 ? -v : v); sum_q += v;
 		}
 		shift = 0;
@@ -90,8 +95,14 @@ __device__ __forceinline__ void quantize_and_emit(CandWriter &cw, const float (&
 	const uint32_t wide = (bps + eff + lg <= 32u) ? 0u : 1u;
 	// |prediction| <= (sum_abs * 2^(bps - 1)) >> shift for samples of bps bits
 	const uint32_t bounded = ((((unsigned long long)sum_abs << (bps - 1u)) >> shift) < (1ull << 27)) ? 1u : 0u;
-	cw.coef(cw.qrows, sum_q);
-	cw.emit(FA_CAND_PACK(1u, order, eff, (uint32_t)shift, rice_k, wide) | (bounded << 23));
+	rec[0] = FA_CAND_PACK(1u, order, eff, (uint32_t)shift, rice_k, wide) | (bounded << 23);
+	if(cw.n < cw.max_cand) {
+		uint4 *dst = (uint4*)(cw.hdr + (size_t)cw.n * cw.stride);   // records start on 16-byte borders and are whole numbers of them long
+#pragma unroll
+		for(int t = 0; t < (MAXORD + 4) / 4; t++) if((uint32_t)(4 * t) <= order) dst[t] = make_uint4(rec[4 * t], rec[4 * t + 1], rec[4 * t + 2], rec[4 * t + 3]);
+		cw.q[(size_t)cw.n * cw.stride + cw.qrows] = sum_q;   // (behind the coefficients of the longest predictor: after the stores above, which may cover its place)
+	}
+	cw.n++;
 }
 
 // One Levinson step i (order i+1): updates lpc[], err; lpc.c:124-146.

@@ -27,15 +27,22 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
 }
 
 // SPILL: blocks too long for an LDS copy of the signal; the differences re-read the PCM instead (cache hits)
+// which: 0 every frame of the batch; 1 the batch's last frame alone; 2 the short frames listed in FaWork::short_list
+// (the full-length frames then have the kernel further down that reads a frame once for all its channels)
 template<bool SPILL>
-__global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w)
+__global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ pcm, FaCfg c, FaWork w, uint32_t which)
 {
 	extern __shared__ __align__(16) int32_t xs[];
 	__shared__ uint32_t s_or, s_ne;
 	__shared__ unsigned long long s_err[5];
 
-	const uint32_t g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig), f = g / c.nsig, s = g - f * c.nsig;   // the signals of a frame share an XCD
+	uint32_t g;
+	if(which == 0u) g = fa_xcd_signal(blockIdx.x, gridDim.x, c.nsig);   // the signals of a frame share an XCD
+	else if(which == 1u) g = (c.F - 1u) * c.nsig + blockIdx.x;
+	else g = w.short_list[blockIdx.x / c.nsig] * c.nsig + blockIdx.x % c.nsig;
+	const uint32_t f = g / c.nsig, s = g - f * c.nsig;
 	const uint32_t n = fa_frame_len(c, w, f);
+	if(which == 2u && n == c.N) return;
 	const uint64_t base = (uint64_t)f * c.N;
 	const uint32_t tid = threadIdx.x;
 
@@ -121,6 +128,95 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 		unsigned long long v = s_err[tid];
 		if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
 		w.fixed_err[(size_t)tid * c.G + g] = v;
+	}
+}
+
+// ---- independent channels of 32-bit words: one workgroup per FRAME, every channel from one read ------
+//
+// The kernel above fetches an interleaved frame once per channel and uses one word in C of every cache line it pulls
+// through L1; for eight channels that traffic, not the arithmetic, is what it takes its time over.  Here a workgroup
+// takes the frame in pieces of PL_CHUNK samples: the piece is read as it lies (16 bytes per thread and load, every line
+// once) and put into LDS channel by channel, then wave v goes through channels v, v + 4, ... with one run of eight
+// samples per lane, by the same successive differences as above.  A channel belongs to one wave from the first piece
+// to the last, so its sums, the OR of its samples and "differs from the first sample" need one reduction over the
+// wave at the end and nothing shared.  Wasted bits are taken out of the sums afterwards (all samples of a channel
+// share their trailing zeros, so every difference does; samples of at most 25 bits: nothing wraps).
+// Full-length frames only; blocksize a multiple of PL_CHUNK.
+#define PL_CHUNK 512
+#define PL_ROW (PL_CHUNK + 4)     // four samples of history in front of a channel's piece
+template<int C>
+__global__ void __launch_bounds__(256) fa_prep_planar_kernel(const int32_t *__restrict__ pcm, FaCfg c, FaWork w)
+{
+	constexpr int SLOTS = (C + 3) / 4;   // channels per wave
+	__shared__ __align__(16) int32_t xs[C][PL_ROW];
+	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	if(fa_frame_len(c, w, f) != c.N) return;     // short frames go to the kernel above
+	const int32_t *__restrict__ src = pcm + (size_t)f * c.N * C;
+	unsigned long long e[SLOTS][5];
+	uint32_t orv[SLOTS], ne[SLOTS]; int32_t first[SLOTS];
+#pragma unroll
+	for(int q = 0; q < SLOTS; q++) { orv[q] = 0; ne[q] = 0; first[q] = 0; for(int k = 0; k < 5; k++) e[q][k] = 0; }
+	const uint32_t B = 0x80000000u;
+	for(uint32_t i0 = 0; i0 < c.N; i0 += PL_CHUNK) {
+		// the piece as it lies: PL_CHUNK * C words, four to a load
+		const uint4 *p4 = (const uint4*)(src + (size_t)i0 * C);
+#pragma unroll
+		for(int k = 0; k < C / 2 + (C & 1); k++) {
+			const uint32_t u = tid + 256u * (uint32_t)k;
+			if((C & 1) == 0 || u < (uint32_t)(PL_CHUNK * C / 4)) {
+				const uint4 v = p4[u];
+				const uint32_t flat = 4u * u, smp = flat / (uint32_t)C, ch = flat - smp * (uint32_t)C;
+				const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+				uint32_t sm = smp, cc = ch;
+#pragma unroll
+				for(int j = 0; j < 4; j++) { xs[cc][4u + sm] = (int32_t)vv[j]; if(++cc == (uint32_t)C) { cc = 0; sm++; } }
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for(int q = 0; q < SLOTS; q++) {
+			const uint32_t ch = wv + 4u * (uint32_t)q;
+			if(ch < (uint32_t)C) {
+				const int4 *r4 = (const int4*)(&xs[ch][0] + 8u * lane);
+				const int4 h = r4[0], lo = r4[1], hi = r4[2];
+				const uint32_t v[12] = { (uint32_t)h.x, (uint32_t)h.y, (uint32_t)h.z, (uint32_t)h.w, (uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w,
+				                         (uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w };
+				if(i0 == 0u) first[q] = xs[ch][4];
+				if(lane == 63u) *(int4*)&xs[ch][0] = hi;   // the history of the channel's next piece (lane 0 of this wave has read these four words already)
+				const bool head = i0 == 0u && lane == 0u;   // the frame's first four samples: no history, and no part in the sums (fixed.c:229-243 starts at sample 4)
+				uint32_t px = v[3], pd1 = v[3] - v[2], pd2 = pd1 - (v[2] - v[1]), pd3 = pd2 - ((v[2] - v[1]) - (v[1] - v[0]));
+				uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, o = 0, d = 0;
+#pragma unroll
+				for(int j = 0; j < 8; j++) {
+					const uint32_t a = v[4 + j], d1 = a - px, d2 = d1 - pd1, d3 = d2 - pd2;
+					o |= a; d |= a ^ (uint32_t)first[q];
+					if(!head || j >= 4) {
+						a0 = sad_u32(a ^ B, B, a0); a1 = sad_u32(a ^ B, px ^ B, a1); a2 = sad_u32(d1 ^ B, pd1 ^ B, a2);
+						a3 = sad_u32(d2 ^ B, pd2 ^ B, a3); a4 = sad_u32(d3 ^ B, pd3 ^ B, a4);
+					}
+					px = a; pd1 = d1; pd2 = d2; pd3 = d3;
+				}
+				e[q][0] += a0; e[q][1] += a1; e[q][2] += a2; e[q][3] += a3; e[q][4] += a4;
+				orv[q] |= o; ne[q] |= d;
+			}
+		}
+		__syncthreads();   // (the loads of the next piece write words 4 .. PL_ROW - 1 of a row only)
+	}
+#pragma unroll
+	for(int q = 0; q < SLOTS; q++) {
+		const uint32_t ch = wv + 4u * (uint32_t)q;
+		if(ch < (uint32_t)C) {
+			const uint32_t all = wave_or(orv[q]), differs = wave_or(ne[q]);
+			const uint32_t wasted = all ? (uint32_t)__ffs((int)all) - 1u : 0u;
+			const uint32_t g = f * c.nsig + ch;
+#pragma unroll
+			for(int k = 0; k < 5; k++) {
+				unsigned long long v = wave_sum64(e[q][k]) >> wasted;
+				if(!c.wide_fixed) v &= 0xffffffffull;  // fixed.c:234: 32-bit accumulators wrap
+				if(lane == 0) w.fixed_err[(size_t)k * c.G + g] = v;
+			}
+			if(lane == 0) { w.wasted[g] = (uint8_t)wasted; w.is_const[g] = (uint8_t)(differs ? 0 : 1); }
+		}
 	}
 }
 
@@ -437,8 +533,26 @@ extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w,
 		hipLaunchKernelGGL(fa_prep_stereo16_kernel, dim3(c->F), dim3(256), 0, st, (const uint32_t*)pcm, *c, *w, 0u, 0u);
 		return;
 	}
-	if(c->spill) { hipLaunchKernelGGL(fa_prep_kernel<true>, dim3(c->G), dim3(256), 0, st, pcm, *c, *w); return; }
+	if(c->spill) { hipLaunchKernelGGL(fa_prep_kernel<true>, dim3(c->G), dim3(256), 0, st, pcm, *c, *w, 0u); return; }
 	const size_t lds = sizeof(int32_t) * (size_t)c->N;
 	(void)hipFuncSetAttribute((const void*)fa_prep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(fa_prep_kernel<false>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w);
+	// independent channels of 32-bit words in whole pieces: the full-length frames by the kernel that reads a frame once
+	const bool planar = !c->midside && c->nsig == c->channels && c->channels >= 2u && c->channels <= 8u && c->pcm_format == FLACAMD_PCM_S32
+		&& (c->N % PL_CHUNK) == 0 && c->bps <= 25u && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x40000000u);
+	if(planar) {
+		const int32_t *p = (const int32_t*)pcm;
+		switch(c->channels) {
+		case 2: hipLaunchKernelGGL(fa_prep_planar_kernel<2>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		case 3: hipLaunchKernelGGL(fa_prep_planar_kernel<3>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		case 4: hipLaunchKernelGGL(fa_prep_planar_kernel<4>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		case 5: hipLaunchKernelGGL(fa_prep_planar_kernel<5>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		case 6: hipLaunchKernelGGL(fa_prep_planar_kernel<6>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		case 7: hipLaunchKernelGGL(fa_prep_planar_kernel<7>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		default: hipLaunchKernelGGL(fa_prep_planar_kernel<8>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
+		}
+		if(c->multi) { if(c->nshort) hipLaunchKernelGGL(fa_prep_kernel<false>, dim3(c->nshort * c->nsig), dim3(256), lds, st_short, pcm, *c, *w, 2u); }
+		else if(c->last_n != c->N) hipLaunchKernelGGL(fa_prep_kernel<false>, dim3(c->nsig), dim3(256), lds, st_short, pcm, *c, *w, 1u);
+		return;
+	}
+	hipLaunchKernelGGL(fa_prep_kernel<false>, dim3(c->G), dim3(256), lds, st, pcm, *c, *w, 0u);
 }
