@@ -150,14 +150,17 @@ __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict_
 		}
 #pragma unroll
 		for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
-			// which of the 16 bytes can be 0xff: the zero-byte test on the complement marks every such byte (and now and then
-			// one above it, which the comparison below sorts out); about one thread in sixteen has any, so the loop runs once
-			// or twice for a wave instead of sixteen times
+			// which of the 16 bytes can start a sync code - 0xff, then 0xf8 or 0xf9: a byte of z below is zero exactly there, and
+			// the zero-byte test marks every such byte (and now and then one above it, which the comparison below sorts out).
+			// In coded audio that is one position in some thirty thousand, so the loop below hardly ever runs for a wave;
+			// looking for the 0xff alone it ran once or twice for nearly every wave.
 			uint32_t m = 0, found = 0;
 #pragma unroll
 			for(uint32_t j = 0; j < 4; j++) {
-				const uint32_t v = ~wd[q][j];
-				const uint32_t x = (((v - 0x01010101u) & ~v) >> 7) & 0x01010101u;
+				const uint32_t after = j < 3u ? wd[q][j + 1u] : nxt[q];
+				const uint32_t y = __builtin_amdgcn_alignbit(after, wd[q][j], 8);          // the bytes one place on
+				const uint32_t z = ~wd[q][j] | ((y & 0xfefefefeu) ^ 0xf8f8f8f8u);
+				const uint32_t x = (((z - 0x01010101u) & ~z) >> 7) & 0x01010101u;
 				m |= ((x | (x >> 7) | (x >> 14) | (x >> 21)) & 15u) << (4u * j);
 			}
 			while(m) {
@@ -179,8 +182,10 @@ __global__ void __launch_bounds__(256) fd_scan_kernel(const uint8_t *__restrict_
 #pragma unroll
 	for(uint32_t q = 0; q < FD_SCAN_TILES; q++) {
 		cnt[q] = (uint32_t)__popc(mask[q]); inc[q] = cnt[q];
+		if(__any(cnt[q] != 0u ? 1 : 0)) {   // (a wave's kilobyte rarely holds a candidate at all)
 #pragma unroll
-		for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc[q], o, 64); if(lane >= (uint32_t)o) inc[q] += t; }
+			for(int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc[q], o, 64); if(lane >= (uint32_t)o) inc[q] += t; }
+		}
 		if(lane == 63u) s_wave[q][wv] = inc[q];
 	}
 	__syncthreads();
