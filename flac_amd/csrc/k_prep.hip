@@ -52,6 +52,45 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 
 	const int32_t x0 = fa_signal(pcm, c, s, base);
 	uint32_t acc = 0, ne = 0;
+	// one channel: the signal lies as it is, so a thread takes 16 bytes at a time (a block is two rounds of loads then,
+	// not sixteen that each wait for memory)
+	const bool lies_flat = !SPILL && c.channels == 1u && !c.midside && (c.N % 8u) == 0 && ((uintptr_t)pcm % 16u) == 0
+		&& (c.pcm_format == FLACAMD_PCM_S16 || c.pcm_format == FLACAMD_PCM_S32);
+	if(lies_flat) {
+		if(c.pcm_format == FLACAMD_PCM_S16) {
+			const int16_t *src = (const int16_t*)pcm + base;
+			for(uint32_t i = tid * 8u; i < n; i += 2048u) {
+				int32_t v[8];
+				if(i + 8u <= n) {
+					const uint4 q = *(const uint4*)(src + i);
+					const uint32_t d[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+					for(int j = 0; j < 4; j++) { v[2 * j] = (int32_t)(int16_t)(d[j] & 0xffffu); v[2 * j + 1] = (int32_t)d[j] >> 16; }
+					*(int4*)(xs + i) = make_int4(v[0], v[1], v[2], v[3]); *(int4*)(xs + i + 4u) = make_int4(v[4], v[5], v[6], v[7]);
+				}
+				else {
+#pragma unroll
+					for(int j = 0; j < 8; j++) { v[j] = (i + (uint32_t)j < n) ? (int32_t)src[i + (uint32_t)j] : x0; if(i + (uint32_t)j < n) xs[i + (uint32_t)j] = v[j]; }
+				}
+#pragma unroll
+				for(int j = 0; j < 8; j++) { acc |= (i + (uint32_t)j < n) ? (uint32_t)v[j] : 0u; ne |= (v[j] != x0) ? 1u : 0u; }
+			}
+		}
+		else {
+			const int32_t *src = (const int32_t*)pcm + base;
+			for(uint32_t i = tid * 4u; i < n; i += 1024u) {
+				int32_t v[4];
+				if(i + 4u <= n) { const int4 q = *(const int4*)(src + i); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; *(int4*)(xs + i) = q; }
+				else {
+#pragma unroll
+					for(int j = 0; j < 4; j++) { v[j] = (i + (uint32_t)j < n) ? src[i + (uint32_t)j] : x0; if(i + (uint32_t)j < n) xs[i + (uint32_t)j] = v[j]; }
+				}
+#pragma unroll
+				for(int j = 0; j < 4; j++) { acc |= (i + (uint32_t)j < n) ? (uint32_t)v[j] : 0u; ne |= (v[j] != x0) ? 1u : 0u; }
+			}
+		}
+	}
+	else
 	for(uint32_t i = tid; i < n; i += 256) {
 		const int32_t v = fa_signal(pcm, c, s, base + i);
 		if constexpr(!SPILL) xs[i] = v;
