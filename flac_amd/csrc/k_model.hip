@@ -14,8 +14,9 @@
 // One lane per signal: each of these recursions is a short strictly sequential chain in
 // double whose rounding must match the reference (no reassociation, no contraction), so
 // there is nothing to spread over a wavefront; the batch supplies the parallelism
-// (frames x signals lanes).  Candidates are written structure-of-arrays ([slot][signal])
-// so that the stores of a wave coalesce.
+// (frames x signals lanes).  A signal's candidate records lie one after the other (header,
+// coefficients, their sum: a whole number of 16-byte pieces each); every lane writes its own
+// signal's, a record at a time in 16-byte stores.
 #include "engine_types.h"
 
 #define FA_LN2 0.69314718055994530942
