@@ -1291,6 +1291,7 @@ extern "C" int flacamd_decoder_create(flacamd_decoder **out, int device, uint32_
 	d->device = device; d->max_bytes = max_bytes;
 	FdCfg &c = d->cfg;
 	c.channels = channels; c.bps = bits_per_sample; c.max_bs = max_blocksize; c.max_frames = max_frames;
+	c.debug = getenv("FLACAMD_DECODE_DEBUG") ? (uint32_t)strtoul(getenv("FLACAMD_DECODE_DEBUG"), 0, 0) : 0u;   // development switches, read when the decoder is made
 	// one lane per frame writes its own row, 64 rows at a time: rows a power of two apart would all land on one
 	// memory channel, so every row is pushed 256 bytes further than the last
 	c.ws_stride = ((max_blocksize + 63u) & ~63u) + 64u;
@@ -1345,7 +1346,6 @@ extern "C" int flacamd_decode_device(flacamd_decoder *d, const void *d_bytes, si
 	hipStream_t st = (hipStream_t)stream;
 	FD_TRY(hipSetDevice(d->device));
 	FdCfg c = d->cfg;
-	{ static const uint32_t dbg = getenv("FLACAMD_DECODE_DEBUG") ? (uint32_t)strtoul(getenv("FLACAMD_DECODE_DEBUG"), 0, 0) : 0u; c.debug = dbg; }
 	c.nbytes = nbytes; c.nscan_wg = (uint32_t)((nbytes + FD_SCAN_BYTES - 1) / FD_SCAN_BYTES); c.pcm_format = (uint32_t)pcm_format; c.pcm_cap = pcm_cap_samples;
 	const uint8_t *bytes = (const uint8_t*)d_bytes;
 	hipLaunchKernelGGL(fd_scan_kernel<false>, dim3((c.nscan_wg + FD_SCAN_TILES - 1u) / FD_SCAN_TILES), dim3(256), 0, st, bytes, c, d->work);

@@ -59,6 +59,34 @@ def test_decoder_handles_false_sync_codes(gpu_engine):
     assert info["frames"] == len(o["frames"]) and np.array_equal(out, pcm)
 
 
+@pytest.mark.parametrize("flag", [0x2, 0x4, 0x8, 0x6])
+def test_alternative_decoder_arrangements_give_the_same_samples(gpu_engine, monkeypatch, flag):
+    """The decode kernel's later forms switched off one by one (the restorer's 16-bit history, taken in fours or one
+    sample at a time; the parser's mode-free step): the forms they replaced still run where a stream calls for them, and
+    must give the same samples.  Music at -8, white noise (verbatim subframes, false sync codes) and a 24-bit stream."""
+    from flac_amd import synth
+    streams = []
+    g = load_golden("st16-level8")
+    streams.append((b"".join(g["frames"]), g["pcm"], 2, 16))
+    noise = synth.white_noise(30000, 2, 16, seed=9)
+    fp, _ = ob.make_params(2, 16, 44100, level=8)
+    o = ob.oracle_encode(fp, noise)
+    streams.append((b"".join(o["frames"]), noise, 2, 16))
+    m24 = synth.multichannel_24(0.4, rate=48000, channels=1, seed=3)
+    fp, _ = ob.make_params(1, 24, 48000, level=8)
+    o = ob.oracle_encode(fp, m24)
+    streams.append((b"".join(o["frames"]), m24, 1, 24))
+    monkeypatch.setenv("FLACAMD_DECODE_DEBUG", hex(flag))
+    try:
+        for blob, pcm, ch, bps in streams:
+            dec = gpu_engine.Decoder(ch, bps, 4096, max_frames=len(blob) // 64 + 256, max_bytes=len(blob))
+            out, _ = dec.decode_host(blob, len(pcm))
+            dec.close()
+            assert np.array_equal(out, np.asarray(pcm).reshape(len(pcm), ch))
+    finally:
+        monkeypatch.delenv("FLACAMD_DECODE_DEBUG")
+
+
 def test_false_candidate_with_a_long_predictor(gpu_engine):
     """Bytes behind the last frame that pass for a frame header whose first subframe claims a predictor of 32
     taps: the candidate is turned down (it runs off the end), the frames before it decode as they are, and the
