@@ -258,6 +258,29 @@ def test_alternative_stage_arrangements_give_the_same_frames(gpu_engine, monkeyp
         assert frames == want and alt == want
 
 
+@pytest.mark.parametrize("flag", [0x40000000, 0x10000000])
+def test_general_kernels_stand_in_for_the_special_ones(gpu_engine, monkeypatch, flag):
+    """Independent channels of 32-bit words have a preparation kernel that reads a frame once for all channels, and
+    one-channel streams take the register-resident autocorrelation kernel with a lane per frame; with either switched
+    off the general kernels do the same work and the frames stay those of the reference encoder."""
+    from flac_amd import synth
+    cases = [(synth.multichannel_24(0.3, rate=96000, channels=6, seed=17), 6, 24, 96000, dict(level=8)),
+             (synth.multichannel_24(0.25, rate=48000, channels=1, seed=18), 1, 24, 48000, dict(level=5)),
+             (synth.music_like(0.6, seed=19)[:, :1].astype(np.int32), 1, 16, 44100, dict(level=8))]
+    for pcm, ch, bps, rate, kw in cases:
+        fp, _ = ob.make_params(ch, bps, rate, **kw)
+        want = ob.oracle_encode(fp, np.asarray(pcm, dtype=np.int32))["frames"]
+        e, (frames, _) = _encode(gpu_engine, ch, bps, rate, kw, pcm)
+        e.close()
+        monkeypatch.setenv("FLACAMD_DEBUG", hex(flag))
+        try:
+            e, (alt, _) = _encode(gpu_engine, ch, bps, rate, kw, pcm)
+            e.close()
+        finally:
+            monkeypatch.delenv("FLACAMD_DEBUG")
+        assert frames == want and alt == want
+
+
 def test_estimate_spot_check_totals(gpu_engine, monkeypatch):
     """The development switch 0x400000 has the pack kernel compare each chosen subframe's estimated size with the bits
     it packs (the reference's SPOTCHECK_ESTIMATE, stream_encoder.c:3444-3473).  Constant subframes are estimated
