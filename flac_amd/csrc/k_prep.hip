@@ -180,14 +180,19 @@ __global__ void __launch_bounds__(256) fa_prep_kernel(const void *__restrict__ p
 // to the last, so its sums, the OR of its samples and "differs from the first sample" need one reduction over the
 // wave at the end and nothing shared.  Wasted bits are taken out of the sums afterwards (all samples of a channel
 // share their trailing zeros, so every difference does; samples of at most 25 bits: nothing wraps).
+// MS: two channels analysed as left, right, mid and side (stream_encoder.c:2051-2058): the two rows are staged the
+// same way and wave v forms signal v from them as it reads.
 // Full-length frames only; blocksize a multiple of PL_CHUNK.
 #define PL_CHUNK 512
 #define PL_ROW (PL_CHUNK + 4)     // four samples of history in front of a channel's piece
-template<int C>
+template<int C, bool MS = false>
 __global__ void __launch_bounds__(256) fa_prep_planar_kernel(const int32_t *__restrict__ pcm, FaCfg c, FaWork w)
 {
-	constexpr int SLOTS = (C + 3) / 4;   // channels per wave
+	static_assert(!MS || C == 2, "mid and side are formed from two channels");
+	constexpr int NSIG = MS ? 4 : C;
+	constexpr int SLOTS = (NSIG + 3) / 4;   // signals per wave
 	__shared__ __align__(16) int32_t xs[C][PL_ROW];
+	__shared__ __align__(16) int32_t s_hist[NSIG][4];   // a signal's last four samples of the piece before (written and read by the signal's own wave)
 	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	if(fa_frame_len(c, w, f) != c.N) return;     // short frames go to the kernel above
 	const int32_t *__restrict__ src = pcm + (size_t)f * c.N * C;
@@ -215,13 +220,28 @@ __global__ void __launch_bounds__(256) fa_prep_planar_kernel(const int32_t *__re
 #pragma unroll
 		for(int q = 0; q < SLOTS; q++) {
 			const uint32_t ch = wv + 4u * (uint32_t)q;
-			if(ch < (uint32_t)C) {
-				const int4 *r4 = (const int4*)(&xs[ch][0] + 8u * lane);
-				const int4 h = r4[0], lo = r4[1], hi = r4[2];
+			if(ch < (uint32_t)NSIG) {
+				// samples 8 lane - 4 .. 8 lane + 7 of the piece; the first lane's four of history are its wave's own keeping
+				int4 h, lo, hi;
+				if constexpr(MS) {
+					const int4 *ra = (const int4*)(&xs[0][0] + 8u * lane), *rb = (const int4*)(&xs[1][0] + 8u * lane);
+					const int4 ha = ra[0], la = ra[1], ia = ra[2], hb = rb[0], lb = rb[1], ib = rb[2];
+					auto form = [&](int32_t l, int32_t r) -> int32_t {   // 32-bit wrapping, like fa_signal
+						return ch == 0u ? l : ch == 1u ? r : ch == 2u ? (int32_t)((uint32_t)l + (uint32_t)r) >> 1 : (int32_t)((uint32_t)l - (uint32_t)r);
+					};
+					h = make_int4(form(ha.x, hb.x), form(ha.y, hb.y), form(ha.z, hb.z), form(ha.w, hb.w));
+					lo = make_int4(form(la.x, lb.x), form(la.y, lb.y), form(la.z, lb.z), form(la.w, lb.w));
+					hi = make_int4(form(ia.x, ib.x), form(ia.y, ib.y), form(ia.z, ib.z), form(ia.w, ib.w));
+				}
+				else {
+					const int4 *r4 = (const int4*)(&xs[ch][0] + 8u * lane);
+					h = r4[0]; lo = r4[1]; hi = r4[2];
+				}
+				if(lane == 0u && i0 != 0u) h = *(const int4*)&s_hist[ch][0];
+				if(lane == 63u) *(int4*)&s_hist[ch][0] = hi;   // (after the first lane's read: the same wave, in program order)
 				const uint32_t v[12] = { (uint32_t)h.x, (uint32_t)h.y, (uint32_t)h.z, (uint32_t)h.w, (uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w,
 				                         (uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w };
-				if(i0 == 0u) first[q] = xs[ch][4];
-				if(lane == 63u) *(int4*)&xs[ch][0] = hi;   // the history of the channel's next piece (lane 0 of this wave has read these four words already)
+				if(i0 == 0u) first[q] = (int32_t)__builtin_amdgcn_readfirstlane((int)lo.x);   // the signal's first sample
 				const bool head = i0 == 0u && lane == 0u;   // the frame's first four samples: no history, and no part in the sums (fixed.c:229-243 starts at sample 4)
 				uint32_t px = v[3], pd1 = v[3] - v[2], pd2 = pd1 - (v[2] - v[1]), pd3 = pd2 - ((v[2] - v[1]) - (v[1] - v[0]));
 				uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, o = 0, d = 0;
@@ -239,12 +259,12 @@ __global__ void __launch_bounds__(256) fa_prep_planar_kernel(const int32_t *__re
 				orv[q] |= o; ne[q] |= d;
 			}
 		}
-		__syncthreads();   // (the loads of the next piece write words 4 .. PL_ROW - 1 of a row only)
+		__syncthreads();
 	}
 #pragma unroll
 	for(int q = 0; q < SLOTS; q++) {
 		const uint32_t ch = wv + 4u * (uint32_t)q;
-		if(ch < (uint32_t)C) {
+		if(ch < (uint32_t)NSIG) {
 			const uint32_t all = wave_or(orv[q]), differs = wave_or(ne[q]);
 			const uint32_t wasted = all ? (uint32_t)__ffs((int)all) - 1u : 0u;
 			const uint32_t g = f * c.nsig + ch;
@@ -576,11 +596,13 @@ extern "C" void fa_launch_prep(const void *pcm, const FaCfg *c, const FaWork *w,
 	const size_t lds = sizeof(int32_t) * (size_t)c->N;
 	(void)hipFuncSetAttribute((const void*)fa_prep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	// independent channels of 32-bit words in whole pieces: the full-length frames by the kernel that reads a frame once
-	const bool planar = !c->midside && c->nsig == c->channels && c->channels >= 2u && c->channels <= 8u && c->pcm_format == FLACAMD_PCM_S32
-		&& (c->N % PL_CHUNK) == 0 && c->bps <= 25u && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x40000000u);
-	if(planar) {
+	const bool whole = c->pcm_format == FLACAMD_PCM_S32 && (c->N % PL_CHUNK) == 0 && ((uintptr_t)pcm % 16u) == 0 && !(c->debug & 0x40000000u);
+	const bool planar = whole && !c->midside && c->nsig == c->channels && c->channels >= 2u && c->channels <= 8u && c->bps <= 25u;
+	const bool planar_ms = whole && c->midside && c->channels == 2u && c->nsig == 4u && c->bps + 1u <= 25u;
+	if(planar || planar_ms) {
 		const int32_t *p = (const int32_t*)pcm;
-		switch(c->channels) {
+		if(planar_ms) hipLaunchKernelGGL((fa_prep_planar_kernel<2, true>), dim3(c->F), dim3(256), 0, st, p, *c, *w);
+		else switch(c->channels) {
 		case 2: hipLaunchKernelGGL(fa_prep_planar_kernel<2>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
 		case 3: hipLaunchKernelGGL(fa_prep_planar_kernel<3>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
 		case 4: hipLaunchKernelGGL(fa_prep_planar_kernel<4>, dim3(c->F), dim3(256), 0, st, p, *c, *w); break;
